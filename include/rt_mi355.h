@@ -1,0 +1,278 @@
+/*
+ * rt_mi355.h — C-ABI of the MI355X-native render hot path (librt_mi355.so).
+ *
+ * This is the drop-in boundary for the ONE accelerated path of fuchsteufelswild/Ray-Tracer:
+ *   boundary #1  RenderStrategy::RenderSceneIntoPPM(Scene*)            (reference src/RenderStrategy.h:16,
+ *                implemented by DefaultRenderer, src/DefaultRenderer.cpp:35-162)
+ *   boundary #2  AccelerationStructure::Intersect(Ray&, SurfaceIntersection&, float)
+ *                                                                       (reference src/AccelerationStructure.h:21,
+ *                implemented by BVHTree, src/BVHTree.cpp:155-206)
+ *
+ * Conventions: plain C, fixed-width PODs, caller owns every host buffer it passes in, the library
+ * owns device memory.  Every entry point returns 0 on success or a negative rt_status; nothing throws
+ * across the ABI.  One context per host thread (not thread-safe).  All matrices are 16 floats in glm
+ * memory order (column-major: m[col*4 + row]) because that is what the reference's Transform stores
+ * (src/acmath.h:983-1070).
+ *
+ * The same input structs are consumed by the CPU oracle (oracle/rt_oracle.cpp), which is test
+ * infrastructure only and shares nothing else with this library.
+ */
+#ifndef RT_MI355_H_
+#define RT_MI355_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 3u
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,     /* bad argument / inconsistent scene description          */
+    RT_ERR_ABI = -2,         /* abi_version mismatch                                    */
+    RT_ERR_NO_DEVICE = -3,   /* no usable HIP device                                    */
+    RT_ERR_HIP = -4,         /* a HIP runtime call failed (see rt_last_error)           */
+    RT_ERR_NO_SCENE = -5,    /* render / intersect called before rt_scene_upload        */
+    RT_ERR_TOO_LARGE = -6    /* request exceeds a documented limit                      */
+} rt_status;
+
+/* ---- materials: reference src/Material.h:11-91, src/brdf.h:9-74, parser src/SceneParser.cpp:280-438 ---- */
+enum { RT_MAT_DEFAULT = 0, RT_MAT_MIRROR = 1, RT_MAT_DIELECTRIC = 2, RT_MAT_CONDUCTOR = 3 };
+enum { RT_BRDF_BLINNPHONG_ORIGINAL = 0, RT_BRDF_BLINNPHONG_MODIFIED = 1, RT_BRDF_PHONG_ORIGINAL = 2,
+       RT_BRDF_PHONG_MODIFIED = 3, RT_BRDF_TORRANCE_SPARROW = 4 };
+
+typedef struct rt_material {
+    int32_t type;             /* RT_MAT_*                                                   */
+    int32_t brdf_kind;        /* RT_BRDF_*                                                  */
+    int32_t brdf_flag;        /* "normalized" (modified BRDFs) or "kdfresnel" (Torrance)    */
+    int32_t degamma;          /* Material::degamma (only scales the mirror weight, Q11)     */
+    float brdf_exponent;      /* BRDFBase::specularPhong                                    */
+    float refraction_index;   /* Material::rIndex                                           */
+    float absorption_index;   /* Conductor::aIndex == BRDFBase::ai                          */
+    float roughness;          /* Material::roughness (glossy reflection, Q15)               */
+    float ka[3];              /* ARC */
+    float kd[3];              /* DRC */
+    float ks[3];              /* SRC */
+    float km[3];              /* MRC */
+    float ac[3];              /* Dielectric::AC */
+    float _pad;
+} rt_material;                /* 96 bytes */
+
+/* ---- lights: reference src/Light.h:14-99, src/Light.cpp:37-129 ---- */
+enum { RT_LIGHT_POINT = 0, RT_LIGHT_DIRECTIONAL = 1, RT_LIGHT_SPOT = 2, RT_LIGHT_AREA = 3 };
+
+typedef struct rt_light {
+    int32_t type;             /* RT_LIGHT_*                                   */
+    float position[3];
+    float intensity[3];       /* intensity or radiance                        */
+    float direction[3];       /* direction (directional, spot) / normal (area) */
+    float coverage_deg;       /* spot */
+    float falloff_deg;        /* spot */
+    float size;               /* area */
+    float _pad[3];
+} rt_light;                   /* 64 bytes */
+
+/* ---- textures: reference src/Texture.h, src/PerlinTextureImpl.cpp, src/ImageTextureImpl.cpp, parser src/SceneParser.cpp:440-595 ---- */
+enum { RT_TEX_IMAGE = 0, RT_TEX_PERLIN = 1 };
+enum { RT_DECAL_REPLACE_KD = 0, RT_DECAL_BLEND_KD = 1, RT_DECAL_REPLACE_ALL = 2, RT_DECAL_REPLACE_NORMAL = 3,
+       RT_DECAL_BUMP_NORMAL = 4, RT_DECAL_REPLACE_BACKGROUND = 5 };
+enum { RT_NOISE_LINEAR = 0, RT_NOISE_ABSVAL = 1 };
+
+typedef struct rt_texture {
+    int32_t kind;             /* RT_TEX_*                                                        */
+    int32_t decal;            /* RT_DECAL_*                                                      */
+    float bump_factor;
+    float noise_scale;        /* perlin                                                          */
+    int32_t noise_conversion; /* RT_NOISE_*                                                      */
+    int32_t normalizer;       /* image: ImageTextureImpl::mNormalizer                            */
+    int32_t width, height;    /* image                                                           */
+    int32_t bilinear;         /* image: always 0 when produced from the reference's parser (Q23) */
+    int32_t texel_is_float;   /* 0: 8-bit RGB (stb_image path), 1: float RGB (EXR path)          */
+    int64_t texel_offset;     /* byte offset of this image inside rt_scene_desc.texels           */
+    int32_t perm[16];         /* perlin: shuffled index table (PerlinTextureImpl::mIndices)      */
+    int32_t _pad[2];
+} rt_texture;                 /* 120 bytes */
+
+/* ---- objects: one per reference Shape that owns a Transform (Sphere, standalone Triangle, Mesh,
+ *      MeshInstance).  It is also the "container shape" identity used by Q26. ---- */
+enum { RT_OBJ_SMOOTH = 1,        /* Shape::ShadingMode::SMOOTH (mesh triangles)                              */
+       RT_OBJ_HAS_XFORM = 2,     /* objTransform != nullptr (standalone <Triangle> passes nullptr)           */
+       RT_OBJ_COMPOSITE = 4 };   /* triangles owned by a Mesh (IsOwnedByComposite, src/Shape.h:116)          */
+
+typedef struct rt_object {
+    float xform[16];          /* Transform::transposeMatrix == object->world matrix M (glm order)  */
+    float motion_blur[3];     /* Shape::motionBlur                                                   */
+    int32_t flags;            /* RT_OBJ_*                                                            */
+    int32_t material;         /* index into materials                                                */
+    int32_t tex_color;        /* ColorChangerTexture index or -1                                     */
+    int32_t tex_normal;       /* NormalChangerTexture index or -1                                    */
+    int32_t _pad;
+} rt_object;                  /* 96 bytes */
+
+#define RT_PRIM_SPHERE 0x40000000   /* bit set in prim_shape[] when the primitive's shape is a sphere     */
+#define RT_PRIM_BLURBOX 0x20000000  /* Primitive::bbox was taken after the motion-blur extension (Q5,Q29) */
+#define RT_PRIM_INDEX_MASK 0x1FFFFFFF
+
+typedef struct rt_scene_desc {
+    uint32_t abi_version;     /* RT_ABI_VERSION */
+    int32_t max_depth;        /* Scene::maxRecursionDepth   */
+    float isect_eps;          /* Scene::intTestEps (Q-cfg)  */
+    float shadow_eps;         /* Scene::shadowRayEps        */
+    float background[3];      /* Scene::backgroundColor     */
+    float ambient[3];         /* Scene::ambientLight        */
+    int32_t bg_texture;       /* texture index or -1        */
+    int32_t _pad0;
+
+    int64_t n_vertices;       /* reference Vertex objects (per mesh, de-duplicated by index, Q28) */
+    const float *vert_pos;    /* [n_vertices][3] object-space positions                          */
+    const float *vert_uv;     /* [n_vertices][2]                                                 */
+
+    int64_t n_triangles;
+    const int32_t *tri_vert;  /* [n_triangles][3] vertex indices */
+    const int32_t *tri_object;/* [n_triangles] object index      */
+
+    int64_t n_spheres;
+    const float *sph_center_radius; /* [n_spheres][4] centre xyz (object space), radius */
+    const int32_t *sph_object;      /* [n_spheres] object index                         */
+
+    int64_t n_objects;
+    const rt_object *objects;
+
+    int64_t n_prims;          /* Scene::primitives, in the reference's push order (Q5)            */
+    const int32_t *prim_shape;/* [n_prims] triangle or sphere index | RT_PRIM_* flags             */
+
+    int32_t n_materials;
+    int32_t n_lights;
+    int32_t n_textures;
+    int32_t _pad1;
+    const rt_material *materials;
+    const rt_light *lights;
+    const rt_texture *textures;
+    const uint8_t *texels;    /* image arena addressed by rt_texture.texel_offset */
+    int64_t texels_bytes;
+} rt_scene_desc;
+
+/* ---- camera: reference src/Camera.h:20-85 (constructor arguments, before SetupCameraCoordinateAxes) ---- */
+typedef struct rt_camera_desc {
+    float position[3];
+    float gaze[3];
+    float up[3];
+    float left, right, bottom, top, distance; /* Camera::ImagePlane */
+    int32_t nx, ny;
+    int32_t num_samples;      /* Camera::nSamples */
+    float focus_distance;
+    float aperture_size;
+} rt_camera_desc;
+
+typedef struct rt_render_opts {
+    uint32_t abi_version;
+    uint32_t seed;            /* key of the counter-based RNG (Philox4x32-10) that replaces Random.h   */
+    int32_t tile_size;        /* interleaved square tiles; <=0 means one tile = whole frame            */
+    int32_t tile_rank;        /* this context renders tiles with (tile_id % tile_world) == tile_rank   */
+    int32_t tile_world;       /* <=1: render every tile                                                */
+    int32_t output_on_device; /* 1: hdr_rgb / prim_id / prim_t are DEVICE pointers (HBM-resident)      */
+    int32_t compact_output;   /* 1: outputs hold only owned pixels, in rt_tile_pixel_order() order      */
+    int32_t max_batch_samples;/* samples traced per wavefront batch; <=0 selects the default (4M)      */
+    int32_t timing;           /* 1: bracket kernels with HIP events and fill rt_stats ms fields        */
+    int32_t _pad;
+} rt_render_opts;
+
+enum { RT_RAY_PRIMARY = 0, RT_RAY_SHADOW = 1, RT_RAY_REFLECT = 2, RT_RAY_REFRACT = 3, RT_RAY_KINDS = 4 };
+
+typedef struct rt_stats {
+    uint64_t rays[RT_RAY_KINDS];  /* closest-hit queries per kind (one "ray" = one AccelerationStructure::Intersect) */
+    uint64_t node_visits;         /* internal nodes whose child boxes were tested   */
+    uint64_t box_tests;           /* child/root boxes slab-tested                   */
+    uint64_t tri_tests;           /* triangle intersection tests                    */
+    uint64_t sphere_tests;        /* sphere intersection tests                      */
+    double ms_total;              /* wall time of the whole rt_render call          */
+    double ms_kernels;            /* HIP-event time first kernel -> last kernel     */
+    double ms_trace;              /* summed HIP-event time of the trace kernels     */
+    uint64_t trace_launches;      /* number of trace-kernel launches                */
+    uint64_t trace_rays;          /* rays processed by those launches               */
+} rt_stats;
+
+typedef struct rt_ray {
+    float origin[3];
+    float direction[3];
+    float time;
+} rt_ray;                         /* 28 bytes */
+
+typedef struct rt_hit {
+    float t;                      /* x-only world parameter (Q2); FLT_MAX when there is no hit       */
+    int32_t shape;                /* triangle index, or sphere index | RT_PRIM_SPHERE, or -1 (no hit) */
+    float ip[3];                  /* world intersection point                                         */
+    float n[3];                   /* world (shading) normal, before any texture tweak                 */
+    float uv[2];
+} rt_hit;                         /* 40 bytes */
+
+typedef struct rt_bvh_info {
+    int64_t n_nodes;              /* internal + leaf nodes of the reference-topology tree */
+    int64_t n_leaves;
+    int32_t max_depth;
+    int32_t _pad;
+    int64_t n_leaf_prims;         /* leaf primitive references after duplicate removal    */
+} rt_bvh_info;
+
+typedef struct rt_ctx rt_ctx;
+
+/* Creates a context bound to HIP device `hip_device_id`.  Fails with RT_ERR_NO_DEVICE when no GPU is
+ * present: there is no CPU fallback.  (Reference: `new DefaultRenderer()`, src/main.cpp:20.) */
+int rt_ctx_create(int hip_device_id, rt_ctx **out);
+
+/* Destroys the context and frees its device memory.  (Reference: `delete renderer`, src/main.cpp:26,
+ * DefaultRenderer::~DefaultRenderer src/DefaultRenderer.cpp:29-33.) */
+void rt_ctx_destroy(rt_ctx *ctx);
+
+/* Last error message of the context (or of rt_ctx_create when ctx == NULL). */
+const char *rt_last_error(const rt_ctx *ctx);
+
+/* Builds the reference-topology BVH on the host, flattens scene + BVH into the device layout and
+ * uploads it.  Replaces DefaultRenderer::RetrieveRenderingParamsFromScene (src/DefaultRenderer.cpp:47-57),
+ * AccelerationStructureFactory::CreateAccelerationStructure (src/AccelerationStructureFactory.cpp:8-21)
+ * and BVHTree::BVHTree/BuildTree (src/BVHTree.cpp:10-153). */
+int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *scene);
+
+/* Describes the BVH of the uploaded scene. */
+int rt_scene_bvh_info(const rt_ctx *ctx, rt_bvh_info *out);
+
+/* Renders one camera of the uploaded scene: replaces DefaultRenderer::RenderCamera up to (not including)
+ * Image::SaveImage (src/DefaultRenderer.cpp:59-162): ray generation, closest-hit traversal, shadow rays,
+ * shading and the reflect/refract recursion as a wavefront pipeline.
+ *   hdr_rgb : [ny*nx*3] float, row-major, the per-pixel mean over samples BEFORE the 8-bit clamp (Q20).
+ *   prim_id : optional [ny*nx] int32, shape hit by the first sample's primary ray (-1 = miss).
+ *   prim_t  : optional [ny*nx] float, its x-only t.
+ * With opts->compact_output the arrays hold rt_owned_pixel_count() entries instead. */
+int rt_render(rt_ctx *ctx, const rt_camera_desc *camera, const rt_render_opts *opts,
+              float *hdr_rgb, int32_t *prim_id, float *prim_t, rt_stats *stats);
+
+/* Batched form of AccelerationStructure::Intersect (src/AccelerationStructure.h:21; BVHTree::Intersect
+ * src/BVHTree.cpp:155): n independent closest-hit queries with the scene's intersection epsilon.
+ * `rays` / `hits` are host pointers unless on_device != 0. */
+int rt_intersect_batch(rt_ctx *ctx, const rt_ray *rays, size_t n, rt_hit *hits, int on_device,
+                       rt_stats *stats);
+
+/* Host-only helpers (no GPU needed). */
+
+/* Number of pixels rendered by (tile_rank, tile_world) and their row-major pixel indices in the order the
+ * compact outputs use (tile by tile, row-major inside a tile).  `out_index` may be NULL. */
+int64_t rt_owned_pixel_count(int nx, int ny, int tile_size, int tile_rank, int tile_world);
+int rt_tile_pixel_order(int nx, int ny, int tile_size, int tile_rank, int tile_world, int32_t *out_index);
+
+/* The Perlin permutation tables the reference would build: std::shuffle(0..15) driven by one
+ * default-constructed std::default_random_engine shared by successive Perlin textures
+ * (src/PerlinTextureImpl.cpp:26-33, src/Scene.h:51, src/SceneParser.cpp:551).  Fills n_tables*16 ints. */
+int rt_perlin_tables(int n_tables, int32_t *out);
+
+/* ObtainColorFromUnclampedVector (src/DefaultRenderer.cpp:18-27): float RGB -> 8-bit, n = pixel count. */
+int rt_resolve_8bit(const float *hdr_rgb, int64_t n_pixels, uint8_t *out_rgb);
+
+uint32_t rt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_MI355_H_ */

@@ -1,0 +1,1447 @@
+/*
+ * rt_oracle.cpp — CPU ORACLE for the render hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A clean-room, quirk-for-quirk restatement (C++11, scalar, recursive, AoS/pointer layout) of the
+ * reference's per-pixel render path, written from reading /root/reference/src as text.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
+ * (ray-tracer_amd/csrc) never links, includes or calls anything in oracle/.
+ *
+ * PARITY STATUS: "parity unpinned" numerically.  The reference ships no tests, golden vectors or KATs
+ *  and building/running it was refused by the environment (binding), so
+ * this restatement cannot be checked bit-for-bit against reference output.  What pins it:
+ *   - the published Philox4x32-10 known-answer vectors (RNG),
+ *   - hand-derived KATs of the restated formulas (tests/test_oracle_kat.py),
+ *   - a loose sanity bound against the author's 8-bit renders the PNGs in src/results/, stored as down-sampled
+ *     fixtures under tests/golden/ (those PNGs come from an older revision of the reference).
+ *
+ * Each function cites the reference file:line it follows.  "Qn" = quirk n of SURVEY.md §8.0.
+ *
+ * Built by oracle/Makefile with the reference's own flags (src/Makefile:1-4: g++ -std=c++11 -O3 -pthread)
+ * plus -ffp-contract=off (x86-64 without -march has no FMA anyway).
+ */
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <random>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "../include/rt_mi355.h"
+
+namespace orc {
+
+// ------------------------------------------------------------------------------------------------
+// Vector math: src/acmath.h:181-371 (Vector3), :550-706 (free functions).  Q1: SqLength() is the
+// Euclidean norm, Length() its square; Normalize divides each component by the norm.
+// ------------------------------------------------------------------------------------------------
+struct V2 { float x, y; };
+struct V3 {
+    float x, y, z;
+    V3() : x(0), y(0), z(0) {}
+    V3(float a, float b, float c) : x(a), y(b), z(c) {}
+    float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+    float &at(int i) { return i == 0 ? x : (i == 1 ? y : z); }
+};
+struct V4 { float x, y, z, w; };
+
+static inline V3 operator+(const V3 &a, const V3 &b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline V3 operator-(const V3 &a, const V3 &b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline V3 operator*(const V3 &a, const V3 &b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline V3 operator*(const V3 &a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+static inline V3 operator*(float s, const V3 &a) { return V3(a.x * s, a.y * s, a.z * s); }   // acmath.h:671 -> v * scalar
+static inline V3 operator/(const V3 &a, float s) { return V3(a.x / s, a.y / s, a.z / s); }
+static inline V3 operator-(const V3 &a) { return V3(-a.x, -a.y, -a.z); }
+static inline float Dot(const V3 &a, const V3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }            // acmath.h:554
+static inline V3 Cross(const V3 &a, const V3 &b) {                                                            // acmath.h:560
+    return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline float Length(const V3 &v) { return v.x * v.x + v.y * v.y + v.z * v.z; }                       // acmath.h:573 (Q1)
+static inline float SqLength(const V3 &v) { return std::sqrt(Length(v)); }                                  // acmath.h:582 (Q1)
+static inline V3 Normalize(const V3 &v) { float l = SqLength(v); return v / l; }                            // acmath.h:591
+static inline V3 MaxElements(const V3 &a, const V3 &b) {                                                     // acmath.h:627
+    return V3(a.x > b.x ? a.x : b.x, a.y > b.y ? a.y : b.y, a.z > b.z ? a.z : b.z);
+}
+static inline V3 MinElements(const V3 &a, const V3 &b) {                                                     // acmath.h:642
+    return V3(a.x < b.x ? a.x : b.x, a.y < b.y ? a.y : b.y, a.z < b.z ? a.z : b.z);
+}
+static inline int MaxElementIndex(const V3 &v) { return v.x > v.y ? (v.x > v.z ? 0 : 2) : (v.y > v.z ? 1 : 2); } // acmath.h:609
+static inline int MinAbsElementIndex(const V3 &v) {                                                          // acmath.h:621
+    return std::abs(v.x) < std::abs(v.y) ? (std::abs(v.x) < std::abs(v.z) ? 0 : 2) : (std::abs(v.y) < std::abs(v.z) ? 1 : 2);
+}
+static inline void SetMax(float &a, const float &b) { a = a < b ? b : a; }                                   // acmath.h:687
+static inline void SetMin(float &a, const float &b) { a = a > b ? b : a; }                                   // acmath.h:690
+static inline float Clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }          // acmath.h:693
+static inline float Lerp(float a, float b, float t) { return (1 - t) * a + t * b; }                          // acmath.h:696
+static inline float Smoothstep(float t) { return 6 * t * t * t * t * t - 15 * t * t * t * t + 10 * t * t * t; } // acmath.h:703
+
+// ------------------------------------------------------------------------------------------------
+// 4x4 matrices in glm memory order m[col][row]; the operation orders restate vendored glm 0.9.8
+// (src/glm/glm/detail/type_mat4x4.inl:500-537 mat*vec, :595-613 mat*mat, func_matrix.inl:296-354 inverse).
+// ------------------------------------------------------------------------------------------------
+struct M4 { float m[4][4]; };
+
+static M4 Identity() { M4 r; for (int c = 0; c < 4; ++c) for (int k = 0; k < 4; ++k) r.m[c][k] = (c == k) ? 1.0f : 0.0f; return r; }
+static bool IsIdentity(const M4 &a) {
+    for (int c = 0; c < 4; ++c) for (int k = 0; k < 4; ++k) if (a.m[c][k] != ((c == k) ? 1.0f : 0.0f)) return false;
+    return true;
+}
+static M4 Transpose(const M4 &a) { M4 r; for (int c = 0; c < 4; ++c) for (int k = 0; k < 4; ++k) r.m[c][k] = a.m[k][c]; return r; }
+static V4 MulV(const M4 &a, const V4 &v) {
+    V4 r;
+    float *o = &r.x;
+    for (int k = 0; k < 4; ++k) {
+        float mul0 = a.m[0][k] * v.x, mul1 = a.m[1][k] * v.y;
+        float add0 = mul0 + mul1;
+        float mul2 = a.m[2][k] * v.z, mul3 = a.m[3][k] * v.w;
+        float add1 = mul2 + mul3;
+        o[k] = add0 + add1;
+    }
+    return r;
+}
+static M4 MulM(const M4 &a, const M4 &b) {
+    M4 r;
+    for (int c = 0; c < 4; ++c)
+        for (int k = 0; k < 4; ++k)
+            r.m[c][k] = ((a.m[0][k] * b.m[c][0] + a.m[1][k] * b.m[c][1]) + a.m[2][k] * b.m[c][2]) + a.m[3][k] * b.m[c][3];
+    return r;
+}
+static M4 Inverse(const M4 &M) {
+    const float(*m)[4] = M.m;
+    float Coef00 = m[2][2] * m[3][3] - m[3][2] * m[2][3];
+    float Coef02 = m[1][2] * m[3][3] - m[3][2] * m[1][3];
+    float Coef03 = m[1][2] * m[2][3] - m[2][2] * m[1][3];
+    float Coef04 = m[2][1] * m[3][3] - m[3][1] * m[2][3];
+    float Coef06 = m[1][1] * m[3][3] - m[3][1] * m[1][3];
+    float Coef07 = m[1][1] * m[2][3] - m[2][1] * m[1][3];
+    float Coef08 = m[2][1] * m[3][2] - m[3][1] * m[2][2];
+    float Coef10 = m[1][1] * m[3][2] - m[3][1] * m[1][2];
+    float Coef11 = m[1][1] * m[2][2] - m[2][1] * m[1][2];
+    float Coef12 = m[2][0] * m[3][3] - m[3][0] * m[2][3];
+    float Coef14 = m[1][0] * m[3][3] - m[3][0] * m[1][3];
+    float Coef15 = m[1][0] * m[2][3] - m[2][0] * m[1][3];
+    float Coef16 = m[2][0] * m[3][2] - m[3][0] * m[2][2];
+    float Coef18 = m[1][0] * m[3][2] - m[3][0] * m[1][2];
+    float Coef19 = m[1][0] * m[2][2] - m[2][0] * m[1][2];
+    float Coef20 = m[2][0] * m[3][1] - m[3][0] * m[2][1];
+    float Coef22 = m[1][0] * m[3][1] - m[3][0] * m[1][1];
+    float Coef23 = m[1][0] * m[2][1] - m[2][0] * m[1][1];
+    float Fac0[4] = {Coef00, Coef00, Coef02, Coef03};
+    float Fac1[4] = {Coef04, Coef04, Coef06, Coef07};
+    float Fac2[4] = {Coef08, Coef08, Coef10, Coef11};
+    float Fac3[4] = {Coef12, Coef12, Coef14, Coef15};
+    float Fac4[4] = {Coef16, Coef16, Coef18, Coef19};
+    float Fac5[4] = {Coef20, Coef20, Coef22, Coef23};
+    float Vec0[4] = {m[1][0], m[0][0], m[0][0], m[0][0]};
+    float Vec1[4] = {m[1][1], m[0][1], m[0][1], m[0][1]};
+    float Vec2[4] = {m[1][2], m[0][2], m[0][2], m[0][2]};
+    float Vec3[4] = {m[1][3], m[0][3], m[0][3], m[0][3]};
+    const float SignA[4] = {+1, -1, +1, -1};
+    const float SignB[4] = {-1, +1, -1, +1};
+    M4 Inv;
+    for (int k = 0; k < 4; ++k) {
+        float Inv0 = (Vec1[k] * Fac0[k] - Vec2[k] * Fac1[k]) + Vec3[k] * Fac2[k];
+        float Inv1 = (Vec0[k] * Fac0[k] - Vec2[k] * Fac3[k]) + Vec3[k] * Fac4[k];
+        float Inv2 = (Vec0[k] * Fac1[k] - Vec1[k] * Fac3[k]) + Vec3[k] * Fac5[k];
+        float Inv3 = (Vec0[k] * Fac2[k] - Vec1[k] * Fac4[k]) + Vec2[k] * Fac5[k];
+        Inv.m[0][k] = Inv0 * SignA[k];
+        Inv.m[1][k] = Inv1 * SignB[k];
+        Inv.m[2][k] = Inv2 * SignA[k];
+        Inv.m[3][k] = Inv3 * SignB[k];
+    }
+    float Dot0x = m[0][0] * Inv.m[0][0], Dot0y = m[0][1] * Inv.m[1][0], Dot0z = m[0][2] * Inv.m[2][0], Dot0w = m[0][3] * Inv.m[3][0];
+    float Dot1 = (Dot0x + Dot0y) + (Dot0z + Dot0w);
+    float OneOverDeterminant = 1.0f / Dot1;
+    for (int c = 0; c < 4; ++c) for (int k = 0; k < 4; ++k) Inv.m[c][k] = Inv.m[c][k] * OneOverDeterminant;
+    return Inv;
+}
+// glm::translate(mat4(1), v) (src/acmath.h:979): fourth column = m0*vx + m1*vy + m2*vz + m3.
+static M4 TranslationMatrix(const V3 &v) {
+    M4 r = Identity();
+    for (int k = 0; k < 4; ++k) {
+        float c0 = (k == 0) ? 1.0f : 0.0f, c1 = (k == 1) ? 1.0f : 0.0f, c2 = (k == 2) ? 1.0f : 0.0f, c3 = (k == 3) ? 1.0f : 0.0f;
+        r.m[3][k] = ((c0 * v.x + c1 * v.y) + c2 * v.z) + c3;
+    }
+    return r;
+}
+
+struct Ray;
+
+// src/acmath.h:983-1070.  transposeMatrix is the object->world matrix M; transformationMatrix = M^T;
+// invTransformationMatrix = inverse(M^T).
+struct Transform {
+    M4 transformationMatrix, invTransformationMatrix, transposeMatrix;
+    Transform() {}
+    explicit Transform(const M4 &pMatrix) : transposeMatrix(pMatrix) { UpdateTransform(); }               // acmath.h:991
+    void UpdateTransform() {                                                                                // acmath.h:998
+        transformationMatrix = Transpose(transposeMatrix);
+        invTransformationMatrix = Inverse(transformationMatrix);
+    }
+    // operator()(const Transformation&) acmath.h:1004: other.transformation * this->transposeMatrix
+    Transform Compose(const M4 &otherTransformation) const { return Transform(MulM(otherTransformation, transposeMatrix)); }
+    V4 Apply(const V4 &vec, bool obj2world = true, bool isDirection = false) const {                        // acmath.h:1016
+        if (isDirection) {
+            if (obj2world) return MulV(invTransformationMatrix, vec);
+            return MulV(Transpose(invTransformationMatrix), vec);
+        }
+        if (obj2world) return MulV(transposeMatrix, vec);
+        return MulV(Transpose(invTransformationMatrix), vec);
+    }
+};
+
+struct Box {
+    V3 min, max;
+    Box() : min(1e9f, 1e9f, 1e9f), max(-1e9f, -1e9f, -1e9f) {}                                               // acmath.h:754
+    Box(const V3 &v0, const V3 &v1) { max = MaxElements(v0, v1); min = MinElements(v0, v1); }                // acmath.h:760
+    float SA() const { V3 e = max - min; return 2 * (e.x * e.y + e.y * e.z + e.x * e.z); }                   // acmath.h:830
+};
+static inline Box Merge(const Box &a, const Box &b) { return Box(MaxElements(a.max, b.max), MinElements(a.min, b.min)); } // acmath.h:922
+static inline Box Merge(const Box &b, const V3 &v) { return Box(MaxElements(b.max, v), MinElements(b.min, v)); }          // acmath.h:932
+static inline float ClippedPosition(const Box &b, const V3 &v, int ax) { return (v[ax] - b.min[ax]) / (b.max[ax] - b.min[ax]); } // acmath.h:942
+
+static inline V3 xyz(const V4 &v) { return V3(v.x, v.y, v.z); }
+static inline V4 v4(const V3 &v, float w) { V4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = w; return r; }
+
+// Transform::operator()(BoundingVolume3f) acmath.h:1034-1050
+static Box TransformBox(const Transform &t, const Box &b) {
+    V3 v0 = xyz(t.Apply(v4(b.min, 1.0f)));
+    Box res(v0, v0);
+    res = Merge(res, xyz(t.Apply(v4(V3(b.max.x, b.min.y, b.min.z), 1.0f))));
+    res = Merge(res, xyz(t.Apply(v4(V3(b.min.x, b.max.y, b.min.z), 1.0f))));
+    res = Merge(res, xyz(t.Apply(v4(V3(b.min.x, b.min.y, b.max.z), 1.0f))));
+    res = Merge(res, xyz(t.Apply(v4(V3(b.min.x, b.max.y, b.max.z), 1.0f))));
+    res = Merge(res, xyz(t.Apply(v4(V3(b.max.x, b.max.y, b.min.z), 1.0f))));
+    res = Merge(res, xyz(t.Apply(v4(V3(b.max.x, b.min.y, b.max.z), 1.0f))));
+    res = Merge(res, xyz(t.Apply(v4(V3(b.max.x, b.max.y, b.max.z), 1.0f))));
+    return res;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Counter-based RNG (replaces src/Random.h per BASELINE.json north_star): Philox4x32-10.
+// key = (seed, pixelIndex), counter = (sampleIndex, pathCode, slot, 0); a draw is the top 24 bits
+// of one output word as an exactly representable value in [0,1).  uniform(a,b) follows libstdc++'s
+// uniform_real_distribution<double>: u*(b-a)+a evaluated in double (src/Random.h:20-24).
+// ------------------------------------------------------------------------------------------------
+static inline void Philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+enum { SLOT_PIXEL = 0, SLOT_TIME = 1, SLOT_GLOSSY = 2, SLOT_LIGHT0 = 3 };
+struct Rng {
+    uint32_t key[2];
+    uint32_t sample;
+    // returns draw `which` (0..3) of slot `slot` on path `path`
+    double U(uint32_t path, uint32_t slot, int which) const {
+        uint32_t ctr[4] = {sample, path, slot, 0u}, out[4];
+        Philox4x32(ctr, key, out);
+        return (double)(out[which] >> 8) * (1.0 / 16777216.0);
+    }
+    double Uniform(uint32_t path, uint32_t slot, int which, double a, double b) const { return U(path, slot, which) * (b - a) + a; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Scene objects
+// ------------------------------------------------------------------------------------------------
+struct Vertex { V3 p, n; V2 uv; int refCount; };                                                             // acmath.h:1077
+
+struct Object {                     // one per reference Shape owning a Transform; also the "container shape"
+    Transform objTransform;
+    bool hasTransform, composite, smooth, activeMotion;
+    V3 motionBlur;
+    int material, texColor, texNormal;
+};
+
+enum ShapeKind { TRIANGLE = 0, SPHERE = 1 };
+
+struct Shape {
+    int kind;
+    int index;                      // triangle index / sphere index in the description
+    Object *obj;
+    // triangle (src/Triangle.h:10-18)
+    Vertex *v0, *v1, *v2;
+    V3 normal, p0p1, p0p2;
+    // sphere (src/Sphere.h:10-11)
+    float radius;
+    V3 center;
+    Box orgBbox;
+};
+
+struct Primitive { Shape *shape; Box bbox; };                                                                // src/Primitive.h:12-31
+
+struct Ray {                                                                                                 // acmath.h:710-743
+    V3 o, d;
+    float currN;                    // currMat->GetRefractionIndex() (only use of Ray::currMat on the path)
+    Object *currShape;
+    float time;
+    // per-(ray, owner mesh) cache of the motion-blur transformed ray (Triangle.cpp:163-184)
+    Object *cacheOwner[4];
+    Transform cacheTransform[4];
+    V3 cacheO[4], cacheD[4];
+    int nCache;
+    Ray() : currN(1.0f), currShape(nullptr), time(0.0f), nCache(0) {}
+    Ray(const V3 &origin, const V3 &dir, float n, Object *s, float t) : o(origin), d(dir), currN(n), currShape(s), time(t), nCache(0) {}
+    V3 At(float t) const { return o + d * t; }                                                               // acmath.h:738
+    float TOf(const V3 &target) const { return (target.x - o.x) / d.x; }                                     // acmath.h:742 (Q2)
+};
+
+struct SurfaceIntersection {                                                                                 // src/Intersection.h:20-58
+    V3 lip, ip, n; V2 uv; V3 rd;
+    float t;
+    int mat;                        // -1 == nullptr (IsValid)
+    Shape *shape;
+    Object *containerShape;
+    int texColor, texNormal;
+    SurfaceIntersection() : t(std::numeric_limits<float>::max()), mat(-1), shape(nullptr), containerShape(nullptr), texColor(-1), texNormal(-1) { uv.x = uv.y = 0; }
+    bool IsValid() const { return mat != -1; }
+};
+
+struct BVHNode {                                                                                             // src/BVHTree.h:17-52
+    BVHNode *left, *right;
+    Box bbox;
+    int axis, startIndex, endIndex;
+    bool IsLeaf() const { return left == nullptr; }
+};
+
+struct Counters {
+    uint64_t rays[RT_RAY_KINDS];
+    uint64_t box_tests, tri_tests, sphere_tests, node_visits;
+    Counters() { std::memset(this, 0, sizeof(*this)); }
+    void Add(const Counters &o) {
+        for (int i = 0; i < RT_RAY_KINDS; ++i) rays[i] += o.rays[i];
+        box_tests += o.box_tests; tri_tests += o.tri_tests; sphere_tests += o.sphere_tests; node_visits += o.node_visits;
+    }
+};
+
+struct Scene {
+    rt_scene_desc d;
+    std::vector<Vertex> vertices;
+    std::vector<Object> objects;
+    std::vector<Shape> triangles, spheres;
+    std::vector<Primitive *> primitives;     // BVHTree::primitives (re-ordered by the build)
+    std::vector<Primitive> primStore;
+    std::vector<rt_material> materials;
+    std::vector<rt_light> lights;
+    std::vector<rt_texture> textures;
+    std::vector<uint8_t> texels;
+    BVHNode *root;
+    int64_t nNodes, nLeaves; int maxDepth;
+    Scene() : root(nullptr), nNodes(0), nLeaves(0), maxDepth(0) {}
+};
+
+// slab test, src/acmath.h:770-820 (Q3)
+static bool BoxIntersect(const Box &b, const Ray &r, float &tn, float &tf) {
+    tn = 0;
+    tf = std::numeric_limits<float>::max();
+    float tnn = (b.min.x - r.o.x) / r.d.x;
+    float tff = (b.max.x - r.o.x) / r.d.x;
+    if (tnn > tff) std::swap(tnn, tff);
+    SetMax(tn, tnn); SetMin(tf, tff);
+    if (tf < tn) return false;
+    tnn = (b.min.y - r.o.y) / r.d.y;
+    tff = (b.max.y - r.o.y) / r.d.y;
+    if (tnn > tff) std::swap(tnn, tff);
+    SetMax(tn, tnn); SetMin(tf, tff);
+    if (tf < tn) return false;
+    tnn = (b.min.z - r.o.z) / r.d.z;
+    tff = (b.max.z - r.o.z) / r.d.z;
+    if (tnn > tff) std::swap(tnn, tff);
+    SetMax(tn, tnn); SetMin(tf, tff);
+    if (tf < tn) return false;
+    return true;
+}
+
+// Transform::operator()(const Ray&, obj2world=false) acmath.h:1053-1069 (Q8)
+static void TransformRay(const Transform &t, const V3 &o, const V3 &d, V3 &oo, V3 &od) {
+    V4 ro = t.Apply(v4(o, 1.0f), false, false);
+    V4 rd = t.Apply(v4(d, 0.0f), false, false);
+    oo = xyz(ro);
+    od = Normalize(xyz(rd));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Triangle, src/Triangle.cpp:115-302
+// ------------------------------------------------------------------------------------------------
+static Transform MotionTransform(const Object &obj, float time) {                                            // Triangle.cpp:170-173, Shape.cpp:73-76
+    V3 timeExtendedMotionBlur = obj.motionBlur * time;
+    return obj.objTransform.Compose(TranslationMatrix(timeExtendedMotionBlur));
+}
+
+static void TriangleTValue(const Shape &s, const V3 &ro, const V3 &rd, bool &hasIntersected, float &t, float &beta, float &gamma, float eps) { // Triangle.cpp:186-250 (Q6)
+    hasIntersected = false;
+    t = 0;
+    V3 r1(s.p0p1.x, s.p0p2.x, rd.x), r2(s.p0p1.y, s.p0p2.y, rd.y), r3(s.p0p1.z, s.p0p2.z, rd.z);
+    V3 p0ro(s.v0->p.x - ro.x, s.v0->p.y - ro.y, s.v0->p.z - ro.z);
+    float detM = r1.x * (r2.y * r3.z - r2.z * r3.y) + r2.x * (r1.z * r3.y - r1.y * r3.z) + r3.x * (r1.y * r2.z - r1.z * r2.y);
+    if (detM == 0.0f) return;
+    float invDetM = 1 / detM;
+    r1.x = p0ro.x; r2.x = p0ro.y; r3.x = p0ro.z;
+    float det1 = r1.x * (r2.y * r3.z - r2.z * r3.y) + r2.x * (r1.z * r3.y - r1.y * r3.z) + r3.x * (r1.y * r2.z - r1.z * r2.y);
+    float v1 = det1 * invDetM;
+    float err = 1 + eps;
+    if (v1 < -eps || v1 > err) return;
+    r1.x = s.p0p1.x; r2.x = s.p0p1.y; r3.x = s.p0p1.z;
+    r1.y = p0ro.x; r2.y = p0ro.y; r3.y = p0ro.z;
+    float det2 = r1.x * (r2.y * r3.z - r2.z * r3.y) + r2.x * (r1.z * r3.y - r1.y * r3.z) + r3.x * (r1.y * r2.z - r1.z * r2.y);
+    float v2 = det2 * invDetM;
+    if (v2 < -eps || v2 > err || v1 + v2 > err) return;
+    r1.y = s.p0p2.x; r2.y = s.p0p2.y; r3.y = s.p0p2.z;
+    r1.z = p0ro.x; r2.z = p0ro.y; r3.z = p0ro.z;
+    float det3 = r1.x * (r2.y * r3.z - r2.z * r3.y) + r2.x * (r1.z * r3.y - r1.y * r3.z) + r3.x * (r1.y * r2.z - r1.z * r2.y);
+    hasIntersected = true;
+    t = det3 * invDetM;
+    beta = v1;
+    gamma = v2;
+}
+
+static void TriangleIntersect(const Shape &s, Ray &rr, SurfaceIntersection &rt, float eps, Counters &cnt) {    // Triangle.cpp:115-139
+    ++cnt.tri_tests;
+    const Object &obj = *s.obj;
+    V3 to = rr.o, td = rr.d;                 // transformedRay = rr
+    const Transform *extended = obj.hasTransform ? &obj.objTransform : nullptr;   // TransformSurfaceValues' choice
+    if (obj.composite) {                     // Triangle.cpp:141-156
+        int hit = -1;
+        for (int i = 0; i < rr.nCache; ++i) if (rr.cacheOwner[i] == s.obj) { hit = i; break; }
+        if (hit >= 0) { to = rr.cacheO[hit]; td = rr.cacheD[hit]; extended = &rr.cacheTransform[hit]; }
+        else if (obj.activeMotion) {         // TransformAndRecordRay, Triangle.cpp:168-184
+            Transform ext = MotionTransform(obj, rr.time);
+            TransformRay(ext, rr.o, rr.d, to, td);
+            if (rr.nCache < 4) {
+                int k = rr.nCache++;
+                rr.cacheOwner[k] = s.obj; rr.cacheTransform[k] = ext; rr.cacheO[k] = to; rr.cacheD[k] = td;
+                extended = &rr.cacheTransform[k];
+            } else {                          // cache full: recompute every time (same values)
+                static thread_local Transform spill;
+                spill = ext; extended = &spill;
+            }
+        } else
+            TransformRay(obj.objTransform, rr.o, rr.d, to, td);
+    } else {                                 // Shape::TransformRayIntoObjectSpace, Shape.cpp:67-82
+        if (obj.hasTransform) {
+            if (obj.activeMotion) {
+                static thread_local Transform tmp;
+                tmp = MotionTransform(obj, rr.time);
+                TransformRay(tmp, rr.o, rr.d, to, td);
+                extended = &tmp;             // Triangle.cpp:282-289
+            } else
+                TransformRay(obj.objTransform, rr.o, rr.d, to, td);
+        }
+    }
+    float t, beta = 0, gamma = 0;
+    bool hasIntersected;
+    TriangleTValue(s, to, td, hasIntersected, t, beta, gamma, eps);
+    if (hasIntersected && t >= -eps) {
+        V3 intersectionPoint = to + td * t;
+        V3 surfaceNormal = s.normal;
+        V3 localIntersectionPoint = intersectionPoint;
+        // CalculateSurfaceValues(1 + eps, ...) Triangle.cpp:252-266
+        float e = 1 + eps;
+        V2 uv;
+        float w0 = e - beta - gamma;
+        uv.x = s.v0->uv.x * w0 + s.v1->uv.x * beta + s.v2->uv.x * gamma;
+        uv.y = s.v0->uv.y * w0 + s.v1->uv.y * beta + s.v2->uv.y * gamma;
+        if (obj.smooth) {
+            surfaceNormal = s.v0->n * w0 + s.v1->n * beta + s.v2->n * gamma;
+            surfaceNormal = Normalize(surfaceNormal);
+        }
+        // TransformSurfaceValues Triangle.cpp:268-302.  A standalone <Triangle> has objTransform == nullptr and
+        // the reference dereferences it here (crash); the intended behaviour "no transform" is restated.
+        if (extended && !IsIdentity(extended->transformationMatrix)) {
+            intersectionPoint = xyz(extended->Apply(v4(intersectionPoint, 1.0f), true));
+            surfaceNormal = xyz(extended->Apply(v4(surfaceNormal, 0.0f), true, true));
+            surfaceNormal = Normalize(surfaceNormal);
+        }
+        t = rr.TOf(intersectionPoint);
+        rt = SurfaceIntersection();
+        rt.lip = localIntersectionPoint; rt.ip = intersectionPoint; rt.n = surfaceNormal; rt.uv = uv;
+        rt.rd = Normalize(rr.o - intersectionPoint);
+        rt.t = t; rt.mat = obj.material; rt.shape = const_cast<Shape *>(&s); rt.containerShape = s.obj;
+        rt.texColor = obj.texColor; rt.texNormal = obj.texNormal;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sphere, src/Sphere.cpp:31-131 (Q9)
+// ------------------------------------------------------------------------------------------------
+static const double PI_D = 3.14159265;                                                                       // src/Shape.h:9
+
+static void SphereIntersect(const Shape &s, Ray &rr, SurfaceIntersection &rt, Counters &cnt) {
+    ++cnt.sphere_tests;
+    const Object &obj = *s.obj;
+    V3 ro = rr.o, rd = rr.d;
+    Transform transformObject = obj.objTransform;
+    if (obj.activeMotion) {                  // Shape.cpp:71-79 / Sphere.cpp:120-126
+        transformObject = MotionTransform(obj, rr.time);
+        TransformRay(transformObject, rr.o, rr.d, ro, rd);
+    } else
+        TransformRay(obj.objTransform, rr.o, rr.d, ro, rd);
+    // CalculateTValueForIntersection Sphere.cpp:61-91
+    V3 originToCenter = ro - s.center;
+    float dirOtC = Dot(originToCenter, rd);
+    float dd = Dot(rd, rd);
+    float discriminant = dirOtC * dirOtC - dd * (Dot(originToCenter, originToCenter) - s.radius * s.radius);
+    if (discriminant < 0) return;
+    discriminant = std::sqrt(discriminant);
+    float ot = -1 * dirOtC - discriminant;
+    if (ot < 0 || ((-dirOtC + discriminant) < ot && -dirOtC + discriminant > 0)) ot = -1 * dirOtC + discriminant;
+    ot /= dd;
+    if (!(ot > 0)) return;
+    V3 intersectionPoint = ro + rd * ot;
+    V3 surfaceNormal = (intersectionPoint - s.center) / s.radius;
+    // CalculateThetaPhiValuesForPoint Sphere.cpp:98-114 (PI is a double macro)
+    float theta = std::acos((intersectionPoint.y - s.center.y) / s.radius);
+    float phi = std::atan2((intersectionPoint.z - s.center.z), (intersectionPoint.x - s.center.x));
+    V2 uv;
+    uv.x = (float)((-phi + PI_D) / (2 * PI_D));
+    uv.y = (float)(theta / PI_D);
+    theta = (float)(uv.y * PI_D);
+    phi = (float)(PI_D - (2 * PI_D) * uv.x);
+    // TransformSurfaceVariablesIntoWorldSpace Sphere.cpp:116-131 (no identity shortcut)
+    intersectionPoint = xyz(transformObject.Apply(v4(intersectionPoint, 1.0f), true));
+    surfaceNormal = xyz(transformObject.Apply(v4(surfaceNormal, 0.0f), true, true));
+    surfaceNormal = Normalize(surfaceNormal);
+    ot = rr.TOf(intersectionPoint);
+    rt = SurfaceIntersection();
+    rt.lip = V3(theta, phi, 0.0f); rt.ip = intersectionPoint; rt.n = surfaceNormal; rt.uv = uv; rt.rd = V3();
+    rt.t = ot; rt.mat = obj.material; rt.shape = const_cast<Shape *>(&s); rt.containerShape = s.obj;
+    rt.texColor = obj.texColor; rt.texNormal = obj.texNormal;
+}
+
+static inline void ShapeIntersect(const Shape &s, Ray &r, SurfaceIntersection &rt, float eps, Counters &cnt) {
+    if (s.kind == TRIANGLE) TriangleIntersect(s, r, rt, eps, cnt); else SphereIntersect(s, r, rt, cnt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// BVH build, src/BVHTree.cpp:10-153
+// ------------------------------------------------------------------------------------------------
+static const int partitionCount = 4;                                                                         // BVHTree.h:57
+
+static void BuildTree(Scene &sc, int start, int end, BVHNode *currentNode, int depth) {
+    std::vector<Primitive *> &primitives = sc.primitives;
+    ++sc.nNodes;
+    if (depth > sc.maxDepth) sc.maxDepth = depth;
+    int primCount = end - start;
+    auto BuildLeaf = [&](int ax, int s, int e, const Box &box) {
+        currentNode->axis = ax; currentNode->startIndex = s; currentNode->endIndex = e;
+        currentNode->left = currentNode->right = nullptr; currentNode->bbox = box; ++sc.nLeaves;
+    };
+    if (primCount <= 1) {
+        V3 boxCenter = (primitives[start]->bbox.max + primitives[start]->bbox.min) * 0.5f;
+        BuildLeaf(MaxElementIndex(boxCenter), start, end, primitives[start]->bbox);
+        return;
+    }
+    Box combinedVolume, combinedCenter;
+    for (int i = start; i < end; ++i) {
+        combinedVolume = Merge(combinedVolume, primitives[i]->bbox);
+        combinedCenter = Merge(combinedCenter, (primitives[i]->bbox.max + primitives[i]->bbox.min) * 0.5f);
+    }
+    int splitax = MaxElementIndex(combinedCenter.max - combinedCenter.min);
+    if (std::abs(combinedCenter.max[splitax] - combinedCenter.min[splitax]) < 0.00000001f) {
+        BuildLeaf(splitax, start, end, combinedVolume);
+        return;
+    }
+    struct PartitionInfo { Box partitionBound; int count; PartitionInfo() : count(0) {} };
+    PartitionInfo partitions[partitionCount];
+    for (int i = start; i < end; ++i) {
+        V3 primitiveCenter((primitives[i]->bbox.max + primitives[i]->bbox.min) * 0.5f);
+        float cp = ClippedPosition(combinedCenter, primitiveCenter, splitax);
+        int index = partitionCount * cp;
+        if (index == partitionCount) --index;
+        partitions[index].count++;
+        partitions[index].partitionBound = Merge(partitions[index].partitionBound, primitives[i]->bbox);
+    }
+    auto Plus = [](const PartitionInfo &a, const PartitionInfo &b) {
+        PartitionInfo r; r.partitionBound = Merge(a.partitionBound, b.partitionBound); r.count = a.count + b.count; return r;
+    };
+    float partitionCost[partitionCount];
+    PartitionInfo forwardSum[partitionCount];
+    forwardSum[0] = partitions[0];
+    for (int i = 1; i < partitionCount; ++i) forwardSum[i] = Plus(partitions[i], forwardSum[i - 1]);
+    PartitionInfo backwardSum[partitionCount];
+    backwardSum[partitionCount - 1] = partitions[partitionCount - 1];
+    partitionCost[partitionCount - 1] = 0.125f + (forwardSum[partitionCount - 1].count * forwardSum[partitionCount - 1].partitionBound.SA()) / combinedVolume.SA();
+    for (int i = partitionCount - 2; i >= 0; --i) {
+        backwardSum[i] = Plus(partitions[i], backwardSum[i + 1]);
+        partitionCost[i] = 0.125f + (forwardSum[i].count * forwardSum[i].partitionBound.SA() + backwardSum[i + 1].count * backwardSum[i + 1].partitionBound.SA()) / combinedVolume.SA();
+    }
+    float minCost = 1e9;
+    int index = -1;
+    for (int i = 0; i < partitionCount; ++i)
+        if (minCost > partitionCost[i]) { minCost = partitionCost[i]; index = i; }
+    int midIndex = -1;
+    if (minCost < primCount) {
+        Primitive **mid = std::partition(&primitives[start], &primitives[end - 1] + 1, [=](Primitive *p0) {
+            V3 cen((p0->bbox.max + p0->bbox.min) * 0.5f);
+            int in = partitionCount * ClippedPosition(combinedCenter, cen, splitax);
+            return in <= index;
+        });
+        midIndex = mid - &primitives[start];
+    } else {
+        BuildLeaf(splitax, start, end, combinedVolume);
+        return;
+    }
+    BVHNode *l = new BVHNode(), *r = new BVHNode();
+    BuildTree(sc, start, start + midIndex, l, depth + 1);
+    BuildTree(sc, start + midIndex, end, r, depth + 1);
+    currentNode->axis = splitax; currentNode->startIndex = start; currentNode->endIndex = end;     // BuildInternal BVHTree.h:41-51
+    currentNode->left = l; currentNode->right = r;
+    currentNode->bbox = Merge(l->bbox, r->bbox);
+}
+
+static void ClearTree(BVHNode *n) { if (!n) return; ClearTree(n->left); ClearTree(n->right); delete n; }
+
+// ------------------------------------------------------------------------------------------------
+// BVH traversal, src/BVHTree.cpp:155-206 (Q4): both children always visited, fresh result per child.
+// ------------------------------------------------------------------------------------------------
+static void IntersectThroughHierarchy(const Scene &sc, BVHNode *head, Ray &r, SurfaceIntersection &rt, float eps, Counters &cnt) {
+    if (head == nullptr) return;
+    float tn = 0, tf;
+    ++cnt.box_tests;
+    if (BoxIntersect(head->bbox, r, tn, tf)) {
+        if (head->IsLeaf()) {
+            for (int i = head->startIndex; i < head->endIndex; ++i) {
+                SurfaceIntersection t;
+                ShapeIntersect(*sc.primitives[i]->shape, r, t, eps, cnt);
+                if (t.IsValid() && t.t > 0 && t.t < rt.t - 0.001f) rt = t;
+            }
+        } else {
+            ++cnt.node_visits;
+            SurfaceIntersection leftIntersection, rightIntersection;
+            IntersectThroughHierarchy(sc, head->left, r, leftIntersection, eps, cnt);
+            IntersectThroughHierarchy(sc, head->right, r, rightIntersection, eps, cnt);
+            if (leftIntersection.IsValid() && rightIntersection.IsValid())
+                rt = leftIntersection.t < rightIntersection.t ? leftIntersection : rightIntersection;
+            else if (leftIntersection.IsValid()) rt = leftIntersection;
+            else if (rightIntersection.IsValid()) rt = rightIntersection;
+        }
+    }
+}
+static inline void AccelIntersect(const Scene &sc, Ray &r, SurfaceIntersection &rt, Counters &cnt) {
+    IntersectThroughHierarchy(sc, sc.root, r, rt, sc.d.isect_eps, cnt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Textures (Q22, Q23)
+// ------------------------------------------------------------------------------------------------
+static const V3 kGradients[16] = {                                                                           // PerlinTextureImpl.h:55-71
+    V3(1, 1, 0), V3(-1, 1, 0), V3(1, -1, 0), V3(-1, -1, 0), V3(1, 0, 1), V3(-1, 0, 1), V3(1, 0, -1), V3(-1, 0, -1),
+    V3(0, 1, 1), V3(0, -1, 1), V3(0, 1, -1), V3(0, -1, -1), V3(1, 1, 0), V3(-1, 1, 0), V3(0, -1, 1), V3(0, -1, -1)};
+
+static inline int PerlinShuffled(const rt_texture &tx, int i) {                                              // PerlinTextureImpl.cpp:238-244
+    int res = i % 16;
+    if (res < 0) res += 16;
+    return tx.perm[res];
+}
+static inline V3 PerlinGradient(const rt_texture &tx, int i, int j, int k) {                                 // :233-236
+    return kGradients[PerlinShuffled(tx, i + PerlinShuffled(tx, j + PerlinShuffled(tx, k)))];
+}
+static float PerlinValue(const rt_texture &tx, float u, float v, float z) {                                  // PerlinTextureImpl.cpp:74-140
+    V3 p(u * tx.noise_scale, v * tx.noise_scale, z * tx.noise_scale);
+    const int N = 16;
+    int xFloor = ((int)std::floor(p.x)) % N, yFloor = ((int)std::floor(p.y)) % N, zFloor = ((int)std::floor(p.z)) % N;
+    int xCeil = (xFloor + 1) % N, yCeil = (yFloor + 1) % N, zCeil = (zFloor + 1) % N;
+    int xfc[2] = {xFloor, xCeil}, yfc[2] = {yFloor, yCeil}, zfc[2] = {zFloor, zCeil};
+    float dxf = p.x - ((int)std::floor(p.x)), dyf = p.y - ((int)std::floor(p.y)), dzf = p.z - ((int)std::floor(p.z));
+    float dxc = dxf - 1, dyc = dyf - 1, dzc = dzf - 1;
+    float w0 = Smoothstep(dxf), w1 = Smoothstep(dyf), w2 = Smoothstep(dzf);
+    V3 g0 = PerlinGradient(tx, xfc[0], yfc[0], zfc[0]), g1 = PerlinGradient(tx, xfc[0], yfc[0], zfc[1]);
+    V3 g2 = PerlinGradient(tx, xfc[0], yfc[1], zfc[0]), g3 = PerlinGradient(tx, xfc[0], yfc[1], zfc[1]);
+    V3 g4 = PerlinGradient(tx, xfc[1], yfc[0], zfc[0]), g5 = PerlinGradient(tx, xfc[1], yfc[0], zfc[1]);
+    V3 g6 = PerlinGradient(tx, xfc[1], yfc[1], zfc[0]), g7 = PerlinGradient(tx, xfc[1], yfc[1], zfc[1]);
+    V3 v0(dxf, dyf, dzf), v1(dxf, dyf, dzc), v2(dxf, dyc, dzf), v3(dxf, dyc, dzc);
+    V3 v4_(dxc, dyf, dzf), v5(dxc, dyf, dzc), v6(dxc, dyc, dzf), v7(dxc, dyc, dzc);
+    float l0 = Lerp(Dot(g0, v0), Dot(g4, v4_), w0);
+    float l1 = Lerp(Dot(g2, v2), Dot(g6, v6), w0);
+    float l2 = Lerp(Dot(g1, v1), Dot(g5, v5), w0);
+    float l3 = Lerp(Dot(g3, v3), Dot(g7, v7), w0);
+    float ll0 = Lerp(l0, l1, w1), ll1 = Lerp(l2, l3, w1);
+    float result = Lerp(ll0, ll1, w2);
+    if (tx.noise_conversion == RT_NOISE_ABSVAL) result = std::abs(result);
+    else result = (result + 1) / 2.0f;
+    return result;
+}
+
+static inline int RepeatCoordinate(int c, int lo, int hi) { if (c > hi) return lo; else if (c < lo) return hi; return c; } // TextureReader.cpp:89-95
+static V3 FetchTexel(const Scene &sc, const rt_texture &tx, int row, int column) {                           // TextureReader.cpp:64-77,97-105
+    row = RepeatCoordinate(row, 0, tx.height - 1);
+    column = RepeatCoordinate(column, 0, tx.width - 1);
+    int index = 3 * (row * tx.width + column);
+    if (tx.texel_is_float) {
+        const float *f = reinterpret_cast<const float *>(sc.texels.data() + tx.texel_offset);
+        return V3(f[index], f[index + 1], f[index + 2]);
+    }
+    const uint8_t *b = sc.texels.data() + tx.texel_offset;
+    return V3(b[index], b[index + 1], b[index + 2]);
+}
+static V3 ImageRGB(const Scene &sc, const rt_texture &tx, float u, float v) {                                // TextureValueRetrieveMethod.cpp:20-55
+    if (u > 1.0f) u = u - (int)u;
+    if (v > 1.0f) v = v - (int)v;
+    float rawColumn = u * (tx.width - 1), rawRow = v * (tx.height - 1);
+    if (!tx.bilinear) {
+        int row = (int)round((double)rawRow), column = (int)round((double)rawColumn);
+        return FetchTexel(sc, tx, row, column);
+    }
+    int row = (int)floor((double)rawRow), column = (int)floor((double)rawColumn);
+    float ro = rawRow - row, co = rawColumn - column;
+    return FetchTexel(sc, tx, row, column) * (1 - ro) * (1 - co) + FetchTexel(sc, tx, row + 1, column) * (ro) * (1 - co) +
+           FetchTexel(sc, tx, row, column + 1) * (1 - ro) * (co) + FetchTexel(sc, tx, row + 1, column + 1) * (ro) * (co);
+}
+// Texture::RetrieveRGBFromUV -> impl (Texture.cpp:23-29)
+static V3 TextureRGB(const Scene &sc, const rt_texture &tx, float u, float v, float z) {
+    if (tx.kind == RT_TEX_PERLIN) { float r = PerlinValue(tx, u, v, z); return V3(r, r, r); }
+    return ImageRGB(sc, tx, u, v);
+}
+// TextureImpl::GetBaseTextureColorForColorChange (ImageTextureImpl.cpp:20-23, PerlinTextureImpl.cpp:11-14)
+static V3 TextureBaseColor(const Scene &sc, const rt_texture &tx, const SurfaceIntersection &is) {
+    if (tx.kind == RT_TEX_PERLIN) return TextureRGB(sc, tx, is.ip.x, is.ip.y, is.ip.z);
+    return ImageRGB(sc, tx, is.uv.x, is.uv.y) / (float)tx.normalizer;
+}
+// SurfaceIntersection::GetDiffuseReflectionCoefficient (Intersection.cpp:31-42) + ColorChangerTexture.cpp:19-39
+static V3 DiffuseCoefficient(const Scene &sc, const SurfaceIntersection &is) {
+    const rt_material &m = sc.materials[is.mat];
+    V3 kd(m.kd[0], m.kd[1], m.kd[2]);
+    if (is.texColor < 0) return kd;
+    const rt_texture &tx = sc.textures[is.texColor];
+    if (tx.decal == RT_DECAL_REPLACE_KD) return TextureBaseColor(sc, tx, is);
+    if (tx.decal == RT_DECAL_BLEND_KD) {
+        V3 textureColor = TextureBaseColor(sc, tx, is);
+        V3 r = (kd + textureColor) / 2;
+        r.x = Clampf(r.x, 0.0f, 1.0f); r.y = Clampf(r.y, 0.0f, 1.0f); r.z = Clampf(r.z, 0.0f, 1.0f);
+        return r;
+    }
+    return TextureRGB(sc, tx, is.uv.x, is.uv.y, 0.0f);          // ColorReplacer
+}
+
+// Perlin bump, PerlinTextureImpl.cpp:45-67
+static V3 PerlinTweakedNormal(const rt_texture &tx, const SurfaceIntersection &is) {
+    const float e = 0.001f;
+    float standard = PerlinValue(tx, is.ip.x, is.ip.y, is.ip.z);
+    float xo = PerlinValue(tx, is.ip.x + e, is.ip.y, is.ip.z);
+    float yo = PerlinValue(tx, is.ip.x, is.ip.y + e, is.ip.z);
+    float zo = PerlinValue(tx, is.ip.x, is.ip.y, is.ip.z + e);
+    V3 diff((xo - standard) / e, (yo - standard) / e, (zo - standard) / e);
+    V3 gp = Dot(diff, is.n) * is.n;
+    V3 gn = diff - gp;
+    gn = is.n - gn * tx.bump_factor;
+    return Normalize(gn);
+}
+
+static V3 ImageNormalValue(const Scene &sc, const rt_texture &tx, float u, float v) {                        // ImageTextureImpl.cpp:87-94
+    V3 normal = ImageRGB(sc, tx, u, v) / 255.0f;
+    V3 c((normal.x - 0.5f) * 2.0f, (normal.y - 0.5f) * 2.0f, (normal.z - 0.5f) * 2.0f);
+    return Normalize(c);
+}
+static void ImageColorValues(const Scene &sc, const rt_texture &tx, const V2 &uvIn, float &standard, float &horizontal, float &vertical, float uvOffsetEpsilon) { // :157-176
+    float u = uvIn.x - std::floor(uvIn.x), v = uvIn.y - std::floor(uvIn.y);
+    float multiplier = tx.bump_factor / 255;
+    V3 a = ImageRGB(sc, tx, u, v) * multiplier;
+    V3 h = ImageRGB(sc, tx, u + uvOffsetEpsilon, v) * multiplier;
+    V3 w = ImageRGB(sc, tx, u, v + uvOffsetEpsilon) * multiplier;
+    standard = (a.x + a.y + a.z) / 3; horizontal = (h.x + h.y + h.z) / 3; vertical = (w.x + w.y + w.z) / 3;
+}
+// glm::inverse(mat2) func_matrix.inl:252-269; m[col][row]
+static void Inverse2(const float m[2][2], float o[2][2]) {
+    float OneOverDeterminant = 1.0f / (+m[0][0] * m[1][1] - m[1][0] * m[0][1]);
+    o[0][0] = +m[1][1] * OneOverDeterminant; o[0][1] = -m[0][1] * OneOverDeterminant;
+    o[1][0] = -m[1][0] * OneOverDeterminant; o[1][1] = +m[0][0] * OneOverDeterminant;
+}
+// uvEdgeMatrix (ImageTextureImpl.cpp:67-78): columns (e1.u, e2.u), (e1.v, e2.v) with e = v_i.uv - v0.uv
+static void UVEdgeMatrix(const Shape &tri, float m[2][2], bool negate) {
+    float e1x = -(tri.v0->uv.x - tri.v1->uv.x), e1y = -(tri.v0->uv.y - tri.v1->uv.y);
+    float e2x = -(tri.v0->uv.x - tri.v2->uv.x), e2y = -(tri.v0->uv.y - tri.v2->uv.y);
+    m[0][0] = e1x; m[0][1] = e2x; m[1][0] = e1y; m[1][1] = e2y;
+    if (negate) for (int c = 0; c < 2; ++c) for (int r = 0; r < 2; ++r) m[c][r] = -m[c][r];
+}
+// combined = inv(uvEdge)(2x2) * edge(3 columns of vec2) (glm mat2*mat3x2: type_mat2x2.inl), rows = columns of the result
+static void CombinedRows(const float inv[2][2], const V3 &a /*first edge*/, const V3 &b /*second edge*/, V2 rows[3]) {
+    const float ea[3] = {a.x, a.y, a.z}, eb[3] = {b.x, b.y, b.z};
+    for (int c = 0; c < 3; ++c) {
+        rows[c].x = inv[0][0] * ea[c] + inv[1][0] * eb[c];
+        rows[c].y = inv[0][1] * ea[c] + inv[1][1] * eb[c];
+    }
+}
+static V3 ImageReplacedNormalTriangle(const Scene &sc, const rt_texture &tx, const SurfaceIntersection &is, const Shape &tri) { // :36-55
+    float uvm[2][2], inv[2][2];
+    UVEdgeMatrix(tri, uvm, true);
+    Inverse2(uvm, inv);
+    V2 rows[3];
+    CombinedRows(inv, tri.p0p1, tri.p0p2, rows);
+    V3 tangent = Normalize(V3(rows[0].x, rows[1].x, rows[2].x));
+    V3 bitangent = Normalize(V3(rows[0].y, rows[1].y, rows[2].y));
+    V3 tn = ImageNormalValue(sc, tx, is.uv.x, is.uv.y);
+    // TBN * textureNormal (mat3 * vec3: m[0]*v.x + m[1]*v.y + m[2]*v.z per row)
+    return V3(tangent.x * tn.x + bitangent.x * tn.y + tri.normal.x * tn.z,
+              tangent.y * tn.x + bitangent.y * tn.y + tri.normal.y * tn.z,
+              tangent.z * tn.x + bitangent.z * tn.y + tri.normal.z * tn.z);
+}
+static V3 ImageBumpedNormalTriangle(const Scene &sc, const rt_texture &tx, const SurfaceIntersection &is, const Shape &tri) {   // :96-155
+    // world-space edges: Transform(-edge, obj2world=true) treats the edge as a point with w = 0 (Vector3f -> Vector4f(v, 0))
+    const Transform &T = tri.obj->objTransform;
+    V3 p0p1t = xyz(T.Apply(v4(-tri.p0p1, 0.0f), true)), p0p2t = xyz(T.Apply(v4(-tri.p0p2, 0.0f), true));
+    float uvm[2][2], inv[2][2];
+    UVEdgeMatrix(tri, uvm, false);
+    Inverse2(uvm, inv);
+    V2 rows[3];
+    CombinedRows(inv, p0p1t, p0p2t, rows);
+    V3 tangent = Normalize(V3(rows[0].x, rows[1].x, rows[2].x));
+    V3 bitangent = Normalize(V3(rows[0].y, rows[1].y, rows[2].y));
+    V3 normal = Cross(tangent, bitangent);
+    tangent = tangent - normal * Dot(tangent, normal);
+    bitangent = bitangent - Dot(bitangent, normal) * normal - Dot(tangent, bitangent) * tangent;
+    float standard, horizontal, vertical;
+    ImageColorValues(sc, tx, is.uv, standard, horizontal, vertical, 0.001f);
+    V3 tweakedTangent = tangent + (horizontal - standard) * normal;
+    V3 tweakedBitangent = bitangent + (vertical - standard) * normal;
+    return Cross(tweakedTangent, tweakedBitangent);
+}
+static void SphereTBN(const Shape &sph, const SurfaceIntersection &is, V3 &tangent, V3 &bitangent, V3 &normal) { // :203-228
+    float phi = is.lip.y, theta = is.lip.x, u = is.uv.x, v = is.uv.y;
+    float x = (float)(sph.radius * std::sin(v * PI_D) * std::cos(PI_D - 2 * u * PI_D));
+    float y = (float)(sph.radius * std::cos(v * PI_D));
+    float z = (float)(sph.radius * std::sin(v * PI_D) * std::sin(PI_D - 2 * u * PI_D));
+    V3 T((float)(2 * z * PI_D), .0f, (float)(-2 * x * PI_D));
+    V3 B((float)(y * std::cos(phi) * PI_D), (float)(-sph.radius * std::sin(theta) * PI_D), (float)(y * std::sin(phi) * PI_D));
+    tangent = Normalize(T);
+    bitangent = Normalize(B);
+    normal = is.n;
+    tangent = tangent - normal * Dot(tangent, normal);
+    bitangent = bitangent - Dot(bitangent, normal) * normal - Dot(tangent, bitangent) * tangent;
+}
+static V3 ImageReplacedNormalSphere(const Scene &sc, const rt_texture &tx, const SurfaceIntersection &is, const Shape &sph) {   // :178-188
+    V3 t, b, n;
+    SphereTBN(sph, is, t, b, n);
+    V3 tn = ImageNormalValue(sc, tx, is.uv.x, is.uv.y);
+    V3 r(t.x * tn.x + b.x * tn.y + n.x * tn.z, t.y * tn.x + b.y * tn.y + n.y * tn.z, t.z * tn.x + b.z * tn.y + n.z * tn.z);
+    return Normalize(r);
+}
+static V3 ImageBumpedNormalSphere(const Scene &sc, const rt_texture &tx, const SurfaceIntersection &is, const Shape &sph) {     // :190-243
+    V3 t, b, n;
+    SphereTBN(sph, is, t, b, n);
+    float standard, horizontal, vertical;
+    ImageColorValues(sc, tx, is.uv, standard, horizontal, vertical, 0.002f);
+    float hd = horizontal - standard, vd = vertical - standard;
+    V3 bumped = n - t * hd - b * vd;
+    // glm::normalize = v * inversesqrt(dot(v,v)) with inversesqrt = 1/sqrt (func_geometric.inl, func_exponential.inl)
+    float inv = 1.0f / std::sqrt(Dot(bumped, bumped));
+    bumped = bumped * inv;
+    if (Dot(bumped, n) < 0) bumped = bumped * -1.0f;
+    return bumped;
+}
+// SurfaceIntersection::TweakSurfaceNormal (Intersection.cpp:25-29) -> Shape::GetChangedNormal -> NormalChangerTexture.cpp
+static void TweakSurfaceNormal(const Scene &sc, SurfaceIntersection &is) {
+    if (!is.shape) return;
+    int tn = is.shape->obj->texNormal;
+    if (tn < 0) return;
+    const rt_texture &tx = sc.textures[tn];
+    bool tri = is.shape->kind == TRIANGLE;
+    if (tx.decal == RT_DECAL_REPLACE_NORMAL) {
+        if (tx.kind == RT_TEX_PERLIN) is.n = V3();                                                     // PerlinTextureImpl.cpp:16-24
+        else is.n = tri ? ImageReplacedNormalTriangle(sc, tx, is, *is.shape) : ImageReplacedNormalSphere(sc, tx, is, *is.shape);
+    } else if (tx.decal == RT_DECAL_BUMP_NORMAL) {
+        if (tx.kind == RT_TEX_PERLIN) is.n = PerlinTweakedNormal(tx, is);
+        else is.n = tri ? ImageBumpedNormalTriangle(sc, tx, is, *is.shape) : ImageBumpedNormalSphere(sc, tx, is, *is.shape);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BRDFs, src/brdf.cpp:13-170 (Q17).  All return BRDF*cos(theta).
+// ------------------------------------------------------------------------------------------------
+static const float pi_f = 3.14159265f;                                                                       // brdf.cpp:9
+
+static float TorranceFr(const rt_material &m, float cosb, float ri) {                                        // brdf.cpp:18-46
+    float n1 = 1.0f, n2 = ri;
+    cosb = Clampf(cosb, -1, 1);
+    if (cosb > 0) std::swap(n1, n2); else cosb = -cosb;
+    n1 = ri;
+    float c2 = cosb * cosb;
+    float nk = n1 * n1 + m.absorption_index * m.absorption_index;
+    float n2c = 2 * n1 * cosb;
+    float Rs = (nk - n2c + c2) / (nk + n2c + c2);
+    float Rp = (nk * c2 - n2c + 1) / (nk * c2 + n2c + 1);
+    return 0.5f * (Rs + Rp);
+}
+static V3 BRDF(const rt_material &m, const V3 &wi, const V3 &wo, const V3 &n, const V3 &kd, const V3 &ks, float ri) {
+    const float e = m.brdf_exponent;
+    switch (m.brdf_kind) {
+    case RT_BRDF_BLINNPHONG_ORIGINAL: {                                                                      // brdf.cpp:150-159
+        float cost = Dot(wi, n);
+        if (cost <= 0) return V3();
+        return kd * cost + ks * std::pow(std::max(0.0f, Dot(n, Normalize(wi + wo))), e);
+    }
+    case RT_BRDF_BLINNPHONG_MODIFIED: {                                                                      // brdf.cpp:80-113
+        float cost = Dot(wi, n);
+        if (cost < 0) return V3();
+        if (!((double)std::acos(cost) < pi_f / 2.0)) return V3();
+        if (m.brdf_flag)
+            return (kd * (1.0f / pi_f) + (ks * (e + 8) * std::pow(std::max(0.0f, Dot(n, Normalize(wi + wo))), e) / (8 * pi_f))) * cost;
+        return (kd + ks * std::pow(std::max(0.0f, Dot(n, Normalize(wi + wo))), e)) * cost;
+    }
+    case RT_BRDF_PHONG_ORIGINAL: {                                                                           // brdf.cpp:161-170 (falls off the end -> 0)
+        float cost = Dot(wi, n);
+        if (cost < 0.0f) return V3();
+        if ((double)std::acos(cost) < pi_f / 2.0)
+            return kd * cost + ks * std::pow(Dot(wo, Normalize(wi - 2.0f * n * cost)), e);
+        return V3();
+    }
+    case RT_BRDF_PHONG_MODIFIED: {                                                                           // brdf.cpp:115-148
+        float cost = Dot(wi, n);
+        if (cost < 0.0f) return V3();
+        if (!((double)std::acos(cost) < pi_f / 2.0)) return V3();
+        if (m.brdf_flag)
+            return (kd * (1.0f / pi_f) + ks * (e + 2) * std::pow(Dot(wo, wi - 2.0f * n * cost), e) / (2.0f * pi_f)) * cost;
+        return (kd + ks * std::pow(Dot(wo, wi - 2.0f * n * cost), e)) * cost;
+    }
+    default: {                                                                                               // Torrance-Sparrow brdf.cpp:13-78
+        float cost = Dot(n, wi);
+        if (cost < 0) return V3();
+        if ((double)std::acos(cost) < pi_f / 2.0) {
+            V3 wh = Normalize(wi + wo);
+            float cosa = std::max(0.0f, Dot(n, wh));
+            float cosb = std::max(0.0f, Dot(wo, wh));
+            float cosc = Dot(wo, n);
+            float d = std::pow(cosa, e) * (e + 2) / (2.0f * pi_f);
+            V3 wh2 = Normalize(wi + wo);
+            float g = std::min(1.0f, Dot(n, wh2) * 2.0f / Dot(wo, wh2) * std::min(Dot(n, wo), Dot(n, wi)));
+            if (m.brdf_flag)
+                return (1.0f - TorranceFr(m, cosb, ri)) * kd * (1.0f / pi_f) * cost + ks * g * TorranceFr(m, cosb, ri) * d / (4.0f * cosc);
+            return kd * (1.0f / pi_f) * cost + ks * g * d / (4.0f * cosc);
+        }
+        return V3();
+    }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lights, src/Light.cpp:37-129 (Q16)
+// ------------------------------------------------------------------------------------------------
+static const float deg2radians = 3.1415926f / 180.0f, rad2deg = 180.0f / 3.1415926f;                         // Light.cpp:12-13
+
+static void LightFormulaVariables(const rt_light &L, int lightIndex, const SurfaceIntersection &is, const Rng &rng, uint32_t path, V3 &pointToLight, float &distanceToLight) {
+    V3 pos(L.position[0], L.position[1], L.position[2]);
+    if (L.type == RT_LIGHT_DIRECTIONAL) {                                                                    // Light.cpp:96-101
+        distanceToLight = 1e9;
+        pointToLight = -V3(L.direction[0], L.direction[1], L.direction[2]);
+        pointToLight = Normalize(pointToLight);
+        return;
+    }
+    if (L.type == RT_LIGHT_AREA) {                                                                           // Light.cpp:103-129
+        double param1 = rng.Uniform(path, SLOT_LIGHT0 + lightIndex, 0, 0.0, 1.0);
+        double param2 = rng.Uniform(path, SLOT_LIGHT0 + lightIndex, 1, 0.0, 1.0);
+        param1 -= 0.5; param2 -= 0.5;
+        V3 toRight = ((float)param1 * L.size) * V3(1.0f, 0.0f, 0.0f);
+        V3 toUp = ((float)param2 * L.size) * V3(0.0f, 0.0f, 1.0f);
+        pos = pos + toUp + toRight;
+    }
+    pointToLight = pos - is.ip;                                                                              // Light.cpp:89-94
+    distanceToLight = SqLength(pointToLight);
+    pointToLight = Normalize(pointToLight);
+}
+static V3 LightIntensityAtPoint(const rt_light &L, const V3 &pointToLight, float distanceToLight) {
+    V3 I(L.intensity[0], L.intensity[1], L.intensity[2]);
+    V3 dir(L.direction[0], L.direction[1], L.direction[2]);
+    switch (L.type) {
+    case RT_LIGHT_DIRECTIONAL: return I;                                                                     // Light.cpp:58-61
+    case RT_LIGHT_SPOT: {                                                                                    // Light.cpp:63-77
+        float cosAngle = std::cos(L.coverage_deg * deg2radians / 2);
+        float theta = std::acos(-Dot(pointToLight, dir));
+        float falloff = (std::cos(theta) - cosAngle) / (std::cos(L.falloff_deg * deg2radians / 2) - cosAngle);
+        if (theta * rad2deg > L.coverage_deg / 2) return V3();
+        V3 faded = I / (distanceToLight * distanceToLight);
+        if (theta * rad2deg > L.falloff_deg / 2) faded = faded * falloff;
+        return faded;
+    }
+    case RT_LIGHT_AREA:                                                                                      // Light.cpp:79-82
+        return I * std::abs(Dot(-pointToLight, dir)) * L.size * L.size / (distanceToLight * distanceToLight);
+    default: return I / (distanceToLight * distanceToLight);                                                 // Light.cpp:84-87
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Shading driver + recursion: src/LightContributionCalculator.cpp:46-145, src/RecursiveComputation.cpp:8-228
+// ------------------------------------------------------------------------------------------------
+struct Tracer {
+    const Scene &sc;
+    Counters cnt;
+    Rng rng;
+    explicit Tracer(const Scene &s) : sc(s) {}
+
+    V3 Background() const {                                                                                  // LightContributionCalculator.cpp:147-153 (Q10)
+        if (sc.d.bg_texture >= 0) return TextureRGB(sc, sc.textures[sc.d.bg_texture], 0.0f, 0.0f, 0.0f);
+        return V3(sc.d.background[0], sc.d.background[1], sc.d.background[2]);
+    }
+
+    bool IsShadowed(const SurfaceIntersection &is, const V3 &pointToLight, float distanceToLight, float rayTime) { // :130-145 (Q7)
+        SurfaceIntersection closest;
+        Ray tempRay(is.ip + is.n * sc.d.shadow_eps, pointToLight, 1.0f, nullptr, rayTime);
+        ++cnt.rays[RT_RAY_SHADOW];
+        AccelIntersect(sc, tempRay, closest, cnt);
+        if (closest.IsValid()) {
+            float distanceToClosestObject = SqLength(closest.ip - is.ip);
+            if (distanceToClosestObject > sc.d.shadow_eps && distanceToClosestObject < distanceToLight - sc.d.shadow_eps) return true;
+        }
+        return false;
+    }
+
+    V3 ProcessLights(const SurfaceIntersection &is, const V3 &pointToViewer, float rayTime, uint32_t path) { // :98-124
+        const rt_material &m = sc.materials[is.mat];
+        V3 all;
+        all = all + V3(sc.d.ambient[0], sc.d.ambient[1], sc.d.ambient[2]) * V3(m.ka[0], m.ka[1], m.ka[2]);
+        for (size_t li = 0; li < sc.lights.size(); ++li) {
+            const rt_light &L = sc.lights[li];
+            V3 pointToLight; float distanceToLight;
+            LightFormulaVariables(L, (int)li, is, rng, path, pointToLight, distanceToLight);
+            V3 c;
+            if (!IsShadowed(is, pointToLight, distanceToLight, rayTime)) {
+                // Light::ComputeResultingColorContribution Light.cpp:37-56 (pow(1, gamma) == 1)
+                V3 kd = DiffuseCoefficient(sc, is);
+                V3 ks(m.ks[0], m.ks[1], m.ks[2]);
+                float gammaMultiplier = 1;
+                if (m.degamma) gammaMultiplier = static_cast<float>(std::pow(1, 2.2f));
+                c = BRDF(m, pointToLight, pointToViewer, is.n, kd, ks, m.refraction_index) * LightIntensityAtPoint(L, pointToLight, distanceToLight) * gammaMultiplier;
+            }
+            all = all + c;
+        }
+        return all;
+    }
+
+    // returns "ray hit something"; outColor semantics exactly as CalculateLight (:46-68)
+    bool CalculateLight(Ray &cameraRay, V3 &outColor, int depth, uint32_t path, int rayKind, SurfaceIntersection *primaryOut = nullptr) {
+        SurfaceIntersection intersection;
+        ++cnt.rays[rayKind];
+        AccelIntersect(sc, cameraRay, intersection, cnt);
+        if (primaryOut) *primaryOut = intersection;
+        if (intersection.IsValid()) {
+            if (intersection.texColor >= 0 && sc.textures[intersection.texColor].decal == RT_DECAL_REPLACE_ALL) {
+                outColor = TextureRGB(sc, sc.textures[intersection.texColor], intersection.uv.x, intersection.uv.y, 0.0f);
+            } else {
+                TweakSurfaceNormal(sc, intersection);
+                CalculateContribution(cameraRay, intersection, outColor, depth, path);
+            }
+            return true;
+        }
+        outColor = Background();
+        return false;
+    }
+
+    void CalculateContribution(Ray &cameraRay, SurfaceIntersection &is, V3 &outColor, int depth, uint32_t path) { // :73-91
+        V3 pointToViewer = Normalize(cameraRay.o - is.ip);
+        bool internal = is.containerShape && cameraRay.currShape && is.containerShape == cameraRay.currShape;      // :93-96 (Q26)
+        if (!internal) outColor = outColor + ProcessLights(is, pointToViewer, cameraRay.time, path);
+        if (depth < sc.d.max_depth) {
+            const rt_material &m = sc.materials[is.mat];
+            if (m.type == RT_MAT_DIELECTRIC || m.type == RT_MAT_CONDUCTOR || m.type == RT_MAT_MIRROR)
+                Recursive(m, cameraRay, is, outColor, depth, path, internal);
+        }
+    }
+
+    void Recursive(const rt_material &m, Ray &baseRay, const SurfaceIntersection &is, V3 &outColor, int depth, uint32_t path, bool isRayInsideObject) {
+        const float shadowEps = sc.d.shadow_eps;
+        V3 mPointToViewer = Normalize(baseRay.o - is.ip);                                                    // RecursiveComputation.cpp:28-29
+        V3 N = Normalize(is.n);
+        float mFraction = 0;
+        V3 MRC(m.km[0], m.km[1], m.km[2]);
+
+        auto ViewerReflectionDirection = [&]() { return Normalize(N * 2.0f * Dot(mPointToViewer, N) - mPointToViewer); }; // :119-122
+        auto Glossy = [&](V3 &vrd) {                                                                         // :92-117 (Q15)
+            if (m.roughness > 0) {
+                int mIndex = MinAbsElementIndex(vrd);
+                V3 rprime = vrd;
+                rprime.at(mIndex) = 1.0f;
+                rprime = Normalize(rprime);
+                V3 u = Normalize(Cross(vrd, rprime));
+                V3 v = Normalize(Cross(vrd, u));
+                V3 r1 = static_cast<float>(rng.Uniform(path, SLOT_GLOSSY, 0, -0.5, 0.5)) * u;
+                V3 r2 = static_cast<float>(rng.Uniform(path, SLOT_GLOSSY, 1, -0.5, 0.5)) * v;
+                vrd = Normalize(vrd + m.roughness * (r1 + r2));
+            }
+        };
+        auto PerformReflection = [&](float coefficient) {                                                    // :62-90
+            V3 mirrorColor;
+            V3 vrd = ViewerReflectionDirection();
+            Glossy(vrd);
+            Ray tempRay(is.ip + N * shadowEps, vrd, baseRay.currN, baseRay.currShape, baseRay.time);
+            bool hit = CalculateLight(tempRay, mirrorColor, depth + 1, path * 2 + 1, RT_RAY_REFLECT);
+            if (hit) outColor = outColor + mirrorColor * MRC * coefficient;
+        };
+        auto PerformRefraction = [&]() {                                                                     // :154-228
+            // ComputeFresnel (:203-228)
+            float outsideMatIndex = baseRay.currN;
+            float insideMatIndex = m.refraction_index;
+            if (isRayInsideObject) insideMatIndex = 1;
+            float corr = Dot(baseRay.d, N);
+            corr = Clampf(corr, -1, 1);
+            if (corr > 0) {
+                if (m.type == RT_MAT_CONDUCTOR) std::swap(outsideMatIndex, insideMatIndex);
+                N = -N;
+            } else
+                corr = -corr;
+            float sin1 = std::sqrt(1 - corr * corr);
+            float sin2 = (outsideMatIndex * sin1) / insideMatIndex;
+            float cos2 = std::sqrt(1 - sin2 * sin2);
+            if (m.type == RT_MAT_DIELECTRIC) {                                                               // Material.cpp:13-24
+                float n1 = outsideMatIndex, n2 = insideMatIndex, cos1 = corr;
+                float n2c1 = n2 * cos1, n1c2 = n1 * cos2;
+                float rpll = (n2c1 - n1c2) / (n2c1 + n1c2);
+                float n1c1 = n1 * cos1, n2c2 = n2 * cos2;
+                float rperp = (n1c1 - n2c2) / (n1c1 + n2c2);
+                mFraction = 0.5f * (rpll * rpll + rperp * rperp);
+            } else {                                                                                         // Material.cpp:26-38 (Q13)
+                float n1 = m.refraction_index, cos1 = corr;
+                float c2 = cos1 * cos1;
+                float nk = n1 * n1 + m.absorption_index * m.absorption_index;
+                float n2c = 2 * n1 * cos1;
+                float Rs = (nk - n2c + c2) / (nk + n2c + c2);
+                float Rp = (nk * c2 - n2c + 1) / (nk * c2 + n2c + 1);
+                mFraction = 0.5f * (Rs + Rp);
+            }
+            // ComputeRefractionParameters (:181-201) (Q14)
+            float n1 = outsideMatIndex, n2 = insideMatIndex;
+            float param = n1 / n2;
+            float cost = 1 - corr * corr;
+            float det = 1 - param * param * cost;
+            if (det >= 0) {
+                V3 tiltedRay = Normalize((baseRay.d + N * corr) * (param) - N * std::sqrt(det));
+                bool hit;
+                V3 fractionColor;
+                if (!isRayInsideObject) {
+                    Ray refractionRay(is.ip + -N * shadowEps, tiltedRay, m.refraction_index, is.containerShape, baseRay.time);
+                    hit = CalculateLight(refractionRay, fractionColor, depth + 1, path * 2, RT_RAY_REFRACT);
+                } else {
+                    Ray refractionRay(is.ip + -N * shadowEps, tiltedRay, 1.0f, nullptr, baseRay.time);
+                    hit = CalculateLight(refractionRay, fractionColor, depth + 1, path * 2, RT_RAY_REFRACT);
+                }
+                if (hit) outColor = outColor + fractionColor * (1 - mFraction);
+            } else if (isRayInsideObject)
+                mFraction = 1;
+        };
+
+        if (m.type == RT_MAT_MIRROR) {
+            PerformReflection(m.degamma ? 2.2f : 1.0f);                                                      // :57-60,71-74
+        } else if (m.type == RT_MAT_CONDUCTOR) {                                                             // :51-55
+            PerformRefraction();
+            PerformReflection(mFraction);
+        } else {                                                                                             // dielectric :124-152
+            PerformRefraction();
+            V3 vrd = ViewerReflectionDirection();
+            V3 mirrorColor(0.0f, 0.0f, 0.0f);
+            Ray tempRay(is.ip + N * shadowEps, vrd, baseRay.currN, baseRay.currShape, baseRay.time);
+            CalculateLight(tempRay, mirrorColor, depth + 1, path * 2 + 1, RT_RAY_REFLECT);
+            outColor = outColor + mirrorColor * mFraction;
+            if (isRayInsideObject) {                                                                         // Q12
+                V3 ac(m.ac[0], m.ac[1], m.ac[2]);
+                float distance = baseRay.TOf(is.ip);
+                float absorptionCoefficient = 0.01f * distance;
+                float ecoeff = std::exp(-absorptionCoefficient);
+                V3 k = ecoeff * V3(std::exp(-ac.x * distance), std::exp(-ac.y * distance), std::exp(-ac.z * distance));
+                outColor = outColor * k;
+            }
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Camera, src/Camera.cpp:16-147
+// ------------------------------------------------------------------------------------------------
+struct Camera {
+    V3 m_Pos, m_Gaze, m_Up, m_Right;
+    rt_camera_desc c;
+    float mSinglePixelWidth, mSinglePixelHeight;
+    int mSampleCountSquared; float mSampleWidthHeight;
+    explicit Camera(const rt_camera_desc &cd) : c(cd) {
+        m_Pos = V3(cd.position[0], cd.position[1], cd.position[2]);
+        m_Gaze = V3(cd.gaze[0], cd.gaze[1], cd.gaze[2]);
+        m_Up = V3(cd.up[0], cd.up[1], cd.up[2]);
+        // SetupCameraCoordinateAxes Camera.cpp:48-64
+        m_Gaze = Normalize(m_Gaze);
+        m_Up = Normalize(m_Up);
+        float correlation = Dot(m_Gaze, m_Up);
+        if (correlation > -0.01f && correlation < 0.01f) {
+            m_Up = Normalize(m_Up);
+            m_Right = Normalize(Cross(m_Gaze, m_Up));
+        } else {
+            m_Right = Normalize(Cross(m_Gaze, m_Up));
+            m_Up = Normalize(Cross(m_Right, m_Gaze));
+        }
+        mSinglePixelWidth = (cd.right - cd.left) / cd.nx;                                                    // Camera.cpp:22-23
+        mSinglePixelHeight = (cd.top - cd.bottom) / cd.ny;
+        mSampleCountSquared = std::sqrt(cd.num_samples);                                                     // PixelSampler.cpp:22-24 (Q19)
+        mSampleWidthHeight = 1.0f / mSampleCountSquared;
+    }
+    V3 Direction(int row, int col, float ho, float vo) const {                                               // Camera.cpp:103-125
+        float horizontalMove = c.left + (col + ho) * mSinglePixelWidth;
+        float verticalMove = c.top - (row + vo) * mSinglePixelHeight;
+        return Normalize(m_Gaze * (c.distance) + m_Right * horizontalMove + m_Up * verticalMove);
+    }
+    Ray GenerateRay(int row, int col) const { return Ray(m_Pos, Direction(row, col, 0.5f, 0.5f), 1.0f, nullptr, 0.0f); } // :76-79 (Q21)
+    Ray GenerateRayForPixelSample(int row, int col, int sampleId, const Rng &rng) const {                    // :85-95, PixelSampler.cpp:27-38
+        float sx = (sampleId % mSampleCountSquared) * mSampleWidthHeight;                                    // acmath.h:901-907
+        float sy = (sampleId / mSampleCountSquared) * mSampleWidthHeight;
+        float randX = (float)rng.Uniform(1, SLOT_PIXEL, 0, 0.0f, mSampleWidthHeight);
+        float randY = (float)rng.Uniform(1, SLOT_PIXEL, 1, 0.0f, mSampleWidthHeight);
+        sx += randX; sy += randY;
+        Ray cameraRay(m_Pos, Direction(row, col, sx, sy), 1.0f, nullptr, 0.0f);
+        if (c.aperture_size > 0) {                                                                           // ApplyLensTilt :132-147 (Q25)
+            float arandX = (float)rng.Uniform(1, SLOT_PIXEL, 2, -c.aperture_size / 2.0, c.aperture_size / 2.0);
+            float arandY = (float)rng.Uniform(1, SLOT_PIXEL, 3, -c.aperture_size / 2.0, c.aperture_size / 2.0);
+            V3 moved = m_Pos + m_Right * arandX + m_Up * arandY;
+            float td = c.focus_distance / (Dot(cameraRay.d, m_Gaze));
+            V3 p = cameraRay.At(td);
+            V3 tilted = Normalize(p - moved);
+            cameraRay = Ray(moved, tilted, 1.0f, nullptr, 0.0f);
+        }
+        return cameraRay;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Scene construction from the description (what SceneParser/Mesh/Triangle/Sphere constructors compute)
+// ------------------------------------------------------------------------------------------------
+static Scene *BuildScene(const rt_scene_desc *d) {
+    Scene *sc = new Scene();
+    sc->d = *d;
+    sc->vertices.resize(d->n_vertices);
+    for (int64_t i = 0; i < d->n_vertices; ++i) {
+        Vertex &v = sc->vertices[i];
+        v.p = V3(d->vert_pos[3 * i], d->vert_pos[3 * i + 1], d->vert_pos[3 * i + 2]);
+        v.uv.x = d->vert_uv ? d->vert_uv[2 * i] : 0.0f; v.uv.y = d->vert_uv ? d->vert_uv[2 * i + 1] : 0.0f;
+        v.n = V3(); v.refCount = 0;
+    }
+    sc->objects.resize(d->n_objects);
+    for (int64_t i = 0; i < d->n_objects; ++i) {
+        const rt_object &o = d->objects[i];
+        Object &ob = sc->objects[i];
+        M4 m; std::memcpy(m.m, o.xform, sizeof(m.m));
+        ob.objTransform = Transform(m);
+        ob.hasTransform = (o.flags & RT_OBJ_HAS_XFORM) != 0;
+        ob.composite = (o.flags & RT_OBJ_COMPOSITE) != 0;
+        ob.smooth = (o.flags & RT_OBJ_SMOOTH) != 0;
+        ob.motionBlur = V3(o.motion_blur[0], o.motion_blur[1], o.motion_blur[2]);
+        ob.activeMotion = ob.motionBlur.x != 0 || ob.motionBlur.y != 0 || ob.motionBlur.z != 0;            // Shape.cpp:41-53, Shape.h:111
+        ob.material = o.material; ob.texColor = o.tex_color; ob.texNormal = o.tex_normal;
+    }
+    sc->materials.assign(d->materials, d->materials + d->n_materials);
+    sc->lights.assign(d->lights, d->lights + d->n_lights);
+    sc->textures.assign(d->textures, d->textures + d->n_textures);
+    if (d->texels_bytes > 0) sc->texels.assign(d->texels, d->texels + d->texels_bytes);
+
+    sc->triangles.resize(d->n_triangles);
+    for (int64_t i = 0; i < d->n_triangles; ++i) {                                                           // Triangle.cpp:48-76
+        Shape &s = sc->triangles[i];
+        s.kind = TRIANGLE; s.index = (int)i; s.obj = &sc->objects[d->tri_object[i]];
+        s.v0 = &sc->vertices[d->tri_vert[3 * i]]; s.v1 = &sc->vertices[d->tri_vert[3 * i + 1]]; s.v2 = &sc->vertices[d->tri_vert[3 * i + 2]];
+        s.p0p1 = s.v0->p - s.v1->p;
+        s.p0p2 = s.v0->p - s.v2->p;
+        s.normal = Normalize(Cross(-s.p0p1, -s.p0p2));
+        s.orgBbox = Box(MaxElements(s.v0->p, MaxElements(s.v1->p, s.v2->p)), MinElements(s.v0->p, MinElements(s.v1->p, s.v2->p)));
+        s.radius = 0;
+    }
+    // smooth shading (Mesh.cpp:88-95, Triangle.cpp:78-105, Q28): per object, in triangle order; an object whose
+    // vertices were already regulated (a MeshInstance sharing its base mesh's Vertex objects) must not be smooth-
+    // flagged by the loader (Q27), so every vertex is touched by exactly one smooth object.
+    {
+        std::vector<std::vector<int64_t>> byObject(d->n_objects);
+        for (int64_t i = 0; i < d->n_triangles; ++i)
+            if (sc->objects[d->tri_object[i]].smooth) byObject[d->tri_object[i]].push_back(i);
+        for (auto &list : byObject) {
+            for (int64_t i : list) {
+                Shape &s = sc->triangles[i];
+                s.v0->n = s.v0->n + s.normal; s.v0->refCount++;
+                s.v1->n = s.v1->n + s.normal; s.v1->refCount++;
+                s.v2->n = s.v2->n + s.normal; s.v2->refCount++;
+            }
+            for (int64_t i : list) {
+                Shape &s = sc->triangles[i];
+                Vertex *vs[3] = {s.v0, s.v1, s.v2};
+                for (Vertex *v : vs) if (v->refCount != 0) { v->n = Normalize(v->n); v->refCount = 0; }
+            }
+        }
+    }
+    sc->spheres.resize(d->n_spheres);
+    for (int64_t i = 0; i < d->n_spheres; ++i) {                                                             // Sphere.cpp:9-21
+        Shape &s = sc->spheres[i];
+        s.kind = SPHERE; s.index = (int)i; s.obj = &sc->objects[d->sph_object[i]];
+        s.center = V3(d->sph_center_radius[4 * i], d->sph_center_radius[4 * i + 1], d->sph_center_radius[4 * i + 2]);
+        s.radius = d->sph_center_radius[4 * i + 3];
+        s.orgBbox = Box(s.center + V3(-s.radius, -s.radius, -s.radius), s.center + V3(s.radius, s.radius, s.radius));
+        s.v0 = s.v1 = s.v2 = nullptr;
+    }
+    // primitives: Primitive::bbox = shape->GetBoundingBox() at push time (Primitive.h:21-26, Q5, Q29)
+    sc->primStore.resize(d->n_prims);
+    sc->primitives.resize(d->n_prims);
+    for (int64_t i = 0; i < d->n_prims; ++i) {
+        int32_t ref = d->prim_shape[i];
+        Shape *s = (ref & RT_PRIM_SPHERE) ? &sc->spheres[ref & RT_PRIM_INDEX_MASK] : &sc->triangles[ref & RT_PRIM_INDEX_MASK];
+        Box bbox = s->obj->hasTransform ? TransformBox(s->obj->objTransform, s->orgBbox) : s->orgBbox;
+        if ((ref & RT_PRIM_BLURBOX) && s->obj->activeMotion) {                                              // Shape.cpp:55-65
+            Transform moved = s->obj->objTransform.Compose(TranslationMatrix(s->obj->motionBlur));
+            bbox = Merge(bbox, TransformBox(moved, s->orgBbox));
+        }
+        sc->primStore[i].shape = s; sc->primStore[i].bbox = bbox;
+        sc->primitives[i] = &sc->primStore[i];
+    }
+    if (d->n_prims > 0) {                                                                                    // BVHTree.cpp:10-18
+        sc->root = new BVHNode();
+        BuildTree(*sc, 0, (int)d->n_prims, sc->root, 1);
+    }
+    return sc;
+}
+
+static inline int32_t ShapeId(const Shape *s) { return s->kind == SPHERE ? (s->index | RT_PRIM_SPHERE) : s->index; }
+
+// one pixel: DefaultRenderer::RenderWithOneSample / RenderMultiSampled (src/DefaultRenderer.cpp:106-138)
+static void RenderPixel(Tracer &tr, const Camera &cam, int row, int col, uint32_t seed, float *rgb, int32_t *primId, float *primT) {
+    const rt_camera_desc &c = cam.c;
+    tr.rng.key[0] = seed; tr.rng.key[1] = (uint32_t)(row * c.nx + col);
+    V3 result;
+    SurfaceIntersection first;
+    if (c.num_samples > 1) {
+        V3 sum;
+        for (int s = 0; s < c.num_samples; ++s) {
+            tr.rng.sample = (uint32_t)s;
+            Ray ray = cam.GenerateRayForPixelSample(row, col, s, tr.rng);
+            ray.currN = 1.0f;
+            ray.time = (float)tr.rng.Uniform(1, SLOT_TIME, 0, 0.0, 1.0);                                   // MultiSampledRayGenerator.cpp:29-30
+            V3 color;
+            tr.CalculateLight(ray, color, 0, 1, RT_RAY_PRIMARY, s == 0 ? &first : nullptr);
+            sum = sum + color;
+        }
+        sum = V3(sum.x / c.num_samples, sum.y / c.num_samples, sum.z / c.num_samples);
+        result = sum;
+    } else {
+        tr.rng.sample = 0;
+        Ray r = cam.GenerateRay(row, col);
+        V3 color;
+        tr.CalculateLight(r, color, 0, 1, RT_RAY_PRIMARY, &first);
+        result = color;
+    }
+    rgb[0] = result.x; rgb[1] = result.y; rgb[2] = result.z;
+    if (primId) *primId = first.IsValid() ? ShapeId(first.shape) : -1;
+    if (primT) *primT = first.t;
+}
+
+} // namespace orc
+
+// ====================================================================================================
+// C interface (ctypes-friendly)
+// ====================================================================================================
+extern "C" {
+
+void *orc_scene_create(const rt_scene_desc *d) {
+    if (!d || d->abi_version != RT_ABI_VERSION) return nullptr;
+    return orc::BuildScene(d);
+}
+void orc_scene_destroy(void *h) {
+    orc::Scene *sc = static_cast<orc::Scene *>(h);
+    if (!sc) return;
+    orc::ClearTree(sc->root);
+    delete sc;
+}
+int orc_bvh_info(void *h, rt_bvh_info *out) {
+    orc::Scene *sc = static_cast<orc::Scene *>(h);
+    out->n_nodes = sc->nNodes; out->n_leaves = sc->nLeaves; out->max_depth = sc->maxDepth; out->n_leaf_prims = (int64_t)sc->primitives.size();
+    return 0;
+}
+// Leaves in DFS (left-to-right) order: for leaf i, [start,end) into the re-ordered primitive array; prim_order[k] =
+// shape id of re-ordered primitive k.  Used by tests to compare the product's host build against this one.
+int orc_bvh_leaves(void *h, int64_t *leaf_start_end /*[2*n_leaves]*/, int32_t *prim_order /*[n_prims]*/, float *leaf_box /*[6*n_leaves] or NULL*/) {
+    orc::Scene *sc = static_cast<orc::Scene *>(h);
+    int64_t k = 0;
+    std::vector<orc::BVHNode *> st;
+    if (sc->root) st.push_back(sc->root);
+    while (!st.empty()) {
+        orc::BVHNode *n = st.back(); st.pop_back();
+        if (n->IsLeaf()) {
+            leaf_start_end[2 * k] = n->startIndex; leaf_start_end[2 * k + 1] = n->endIndex;
+            if (leaf_box) { float *b = leaf_box + 6 * k; b[0] = n->bbox.min.x; b[1] = n->bbox.min.y; b[2] = n->bbox.min.z; b[3] = n->bbox.max.x; b[4] = n->bbox.max.y; b[5] = n->bbox.max.z; }
+            ++k;
+        } else { st.push_back(n->right); st.push_back(n->left); }
+    }
+    for (size_t i = 0; i < sc->primitives.size(); ++i) prim_order[i] = orc::ShapeId(sc->primitives[i]->shape);
+    return 0;
+}
+
+// Render rows [row0,row1) of the frame with `nthreads` threads.  dynamic == 0: contiguous row bands exactly like
+// DefaultRenderer::RenderCamera (rowDiff = rows / nthreads, last band takes the remainder, DefaultRenderer.cpp:65-75);
+// dynamic != 0: rows handed out one at a time (used for the all-cores baseline).
+int orc_render(void *h, const rt_camera_desc *cam, uint32_t seed, int nthreads, int dynamic, int row0, int row1,
+               float *hdr_rgb, int32_t *prim_id, float *prim_t, rt_stats *stats) {
+    orc::Scene *sc = static_cast<orc::Scene *>(h);
+    if (!sc || !cam || !hdr_rgb) return RT_ERR_INVALID;
+    if (nthreads < 1) nthreads = 1;
+    orc::Camera camera(*cam);
+    std::vector<orc::Counters> counters(nthreads);
+    std::atomic<int> nextRow(row0);
+    auto work = [&](int tid) {
+        orc::Tracer tr(*sc);
+        auto doRow = [&](int row) {
+            for (int col = 0; col < cam->nx; ++col) {
+                int64_t p = (int64_t)row * cam->nx + col;
+                orc::RenderPixel(tr, camera, row, col, seed, hdr_rgb + 3 * p, prim_id ? prim_id + p : nullptr, prim_t ? prim_t + p : nullptr);
+            }
+        };
+        if (dynamic) {
+            for (;;) { int row = nextRow.fetch_add(1); if (row >= row1) break; doRow(row); }
+        } else {
+            int rows = row1 - row0, rowDiff = rows / nthreads;
+            int a = row0 + rowDiff * tid, b = (tid == nthreads - 1) ? row1 : row0 + rowDiff * (tid + 1);
+            for (int row = a; row < b; ++row) doRow(row);
+        }
+        counters[tid] = tr.cnt;
+    };
+    std::vector<std::thread> threads;
+    for (int t = 0; t < nthreads; ++t) threads.emplace_back(work, t);
+    for (auto &t : threads) t.join();
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        orc::Counters total;
+        for (auto &c : counters) total.Add(c);
+        for (int i = 0; i < RT_RAY_KINDS; ++i) stats->rays[i] = total.rays[i];
+        stats->node_visits = total.node_visits; stats->box_tests = total.box_tests; stats->tri_tests = total.tri_tests; stats->sphere_tests = total.sphere_tests;
+    }
+    return 0;
+}
+
+// Batched AccelerationStructure::Intersect (BVHTree.cpp:155) for parity tests of boundary #2.
+int orc_intersect_batch(void *h, const rt_ray *rays, size_t n, rt_hit *hits) {
+    orc::Scene *sc = static_cast<orc::Scene *>(h);
+    orc::Counters cnt;
+    for (size_t i = 0; i < n; ++i) {
+        orc::Ray r(orc::V3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]), orc::V3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]), 1.0f, nullptr, rays[i].time);
+        orc::SurfaceIntersection is;
+        orc::AccelIntersect(*sc, r, is, cnt);
+        rt_hit &o = hits[i];
+        o.t = is.t; o.shape = is.IsValid() ? orc::ShapeId(is.shape) : -1;
+        o.ip[0] = is.ip.x; o.ip[1] = is.ip.y; o.ip[2] = is.ip.z; o.n[0] = is.n.x; o.n[1] = is.n.y; o.n[2] = is.n.z; o.uv[0] = is.uv.x; o.uv[1] = is.uv.y;
+    }
+    return 0;
+}
+
+// KAT hooks
+void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { orc::Philox4x32(ctr, key, out); }
+float orc_perlin(const rt_texture *tx, float x, float y, float z) { return orc::PerlinValue(*tx, x, y, z); }
+void orc_inverse4(const float *m, float *out) { orc::M4 a; std::memcpy(a.m, m, 64); orc::M4 r = orc::Inverse(a); std::memcpy(out, r.m, 64); }
+int orc_box_intersect(const float *box6, const float *o, const float *d) {
+    orc::Box b; b.min = orc::V3(box6[0], box6[1], box6[2]); b.max = orc::V3(box6[3], box6[4], box6[5]);
+    orc::Ray r(orc::V3(o[0], o[1], o[2]), orc::V3(d[0], d[1], d[2]), 1.0f, nullptr, 0.0f);
+    float tn, tf; return orc::BoxIntersect(b, r, tn, tf) ? 1 : 0;
+}
+void orc_camera_ray(const rt_camera_desc *cam, int row, int col, int sample, uint32_t seed, float *o3, float *d3, float *time) {
+    orc::Camera c(*cam);
+    orc::Rng rng; rng.key[0] = seed; rng.key[1] = (uint32_t)(row * cam->nx + col); rng.sample = (uint32_t)sample;
+    orc::Ray r = cam->num_samples > 1 ? c.GenerateRayForPixelSample(row, col, sample, rng) : c.GenerateRay(row, col);
+    float t = cam->num_samples > 1 ? (float)rng.Uniform(1, orc::SLOT_TIME, 0, 0.0, 1.0) : 0.0f;
+    o3[0] = r.o.x; o3[1] = r.o.y; o3[2] = r.o.z; d3[0] = r.d.x; d3[1] = r.d.y; d3[2] = r.d.z; *time = t;
+}
+uint32_t orc_abi_version(void) { return RT_ABI_VERSION; }
+
+} // extern "C"

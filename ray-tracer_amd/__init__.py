@@ -1,0 +1,5 @@
+"""MI355X-native render hot path of fuchsteufelswild/Ray-Tracer (package directory: ray-tracer_amd).
+
+Import with importlib.import_module("ray-tracer_amd") (the hyphen is the name the project was given).
+"""
+from . import abi, scene  # noqa: F401
