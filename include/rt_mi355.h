@@ -270,6 +270,25 @@ int rt_perlin_tables(int n_tables, int32_t *out);
 /* ObtainColorFromUnclampedVector (src/DefaultRenderer.cpp:18-27): float RGB -> 8-bit, n = pixel count. */
 int rt_resolve_8bit(const float *hdr_rgb, int64_t n_pixels, uint8_t *out_rgb);
 
+/* Host-only view of the BVH that rt_scene_upload would build (reference topology, BVHTree.cpp:39-153), so that tests
+ * can compare it with an independent build without a GPU.  Leaves are listed in left-to-right DFS order.
+ *   leaf_start_end      [2*n_leaves]  range of each leaf in the reference's re-ordered primitive array
+ *   prim_order          [n_prims]     shape id (rt_hit.shape convention) of every re-ordered reference primitive
+ *   leaf_boxes          [6*n_leaves]  min xyz, max xyz
+ *   dev_leaf_start_count[2*n_leaves]  run of each leaf in the device primitive records (duplicates removed)
+ *   dev_prim_shape      [n_leaf_prims] shape id of every device primitive record
+ * Any output pointer may be NULL. */
+typedef struct rt_host_bvh rt_host_bvh;
+int rt_host_bvh_build(const rt_scene_desc *scene, rt_host_bvh **out);
+int rt_host_bvh_info(const rt_host_bvh *bvh, rt_bvh_info *out);
+int rt_host_bvh_leaves(const rt_host_bvh *bvh, int64_t *leaf_start_end, int32_t *prim_order, float *leaf_boxes,
+                       int64_t *dev_leaf_start_count, int32_t *dev_prim_shape);
+void rt_host_bvh_free(rt_host_bvh *bvh);
+
+/* sizeof() of the ABI structs, in header order (0 rt_material, 1 rt_light, 2 rt_texture, 3 rt_object, 4 rt_scene_desc,
+ * 5 rt_camera_desc, 6 rt_render_opts, 7 rt_stats, 8 rt_ray, 9 rt_hit, 10 rt_bvh_info); -1 for anything else. */
+int rt_abi_sizeof(int which);
+
 uint32_t rt_abi_version(void);
 
 #ifdef __cplusplus

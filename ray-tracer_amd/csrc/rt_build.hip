@@ -1,0 +1,317 @@
+// rt_build.hip — host side of rt_scene_upload: what the reference computes in its Shape / Mesh / Primitive
+// constructors and in BVHTree::BuildTree, re-done as flat arrays and emitted in the HBM layout of
+// rt_device.h.  Host code only (no kernels); compiled by hipcc with -ffp-contract=off.
+//
+//   shape setup      src/Triangle.cpp:48-76, src/Sphere.cpp:9-21, src/Mesh.cpp:88-95 (smooth normals, Q28)
+//   world boxes      src/acmath.h:1034-1050, src/Shape.cpp:55-65 (motion-blur extension, Q29), src/Primitive.h:21-26 (Q5)
+//   BVH build        src/BVHTree.cpp:39-153: 4-bin SAH on centroids, std::partition (same libstdc++ call, so the
+//                    re-ordering inside each side is the reference's), leaves keep index ranges
+//   flattening       new: preorder internal nodes with both child boxes, leaves numbered in DFS order (Q4 tie-break)
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "rt_build.h"
+#include "rt_math.h"
+
+namespace {
+
+struct Aabb {
+    f3 lo, hi;
+};
+
+inline Aabb empty_box() { Aabb b; b.lo = mk3(1e9f, 1e9f, 1e9f); b.hi = mk3(-1e9f, -1e9f, -1e9f); return b; }   // acmath.h:754-758
+inline Aabb box_of(f3 a, f3 b) { Aabb r; r.hi = max3(a, b); r.lo = min3(a, b); return r; }                       // acmath.h:760-764
+inline Aabb merge(const Aabb &a, const Aabb &b) { return box_of(max3(a.hi, b.hi), min3(a.lo, b.lo)); }            // acmath.h:922
+inline Aabb merge(const Aabb &a, f3 p) { return box_of(max3(a.hi, p), min3(a.lo, p)); }                          // acmath.h:932
+inline float surface_area(const Aabb &b) { f3 e = b.hi - b.lo; return 2 * (e.x * e.y + e.y * e.z + e.x * e.z); } // acmath.h:830
+inline f3 centroid(const Aabb &b) { return (b.hi + b.lo) * 0.5f; }
+inline int widest_axis(f3 v) { return v.x > v.y ? (v.x > v.z ? 0 : 2) : (v.y > v.z ? 1 : 2); }                   // MaxElementIndex acmath.h:609
+
+// Transform::operator()(BoundingVolume3f) — the 8 corners through M, merged (acmath.h:1034-1050)
+Aabb transform_box(const float *M, const Aabb &b) {
+    f3 c0 = mat_mul_xyz(M, b.lo.x, b.lo.y, b.lo.z, 1.0f);
+    Aabb r = box_of(c0, c0);
+    r = merge(r, mat_mul_xyz(M, b.hi.x, b.lo.y, b.lo.z, 1.0f));
+    r = merge(r, mat_mul_xyz(M, b.lo.x, b.hi.y, b.lo.z, 1.0f));
+    r = merge(r, mat_mul_xyz(M, b.lo.x, b.lo.y, b.hi.z, 1.0f));
+    r = merge(r, mat_mul_xyz(M, b.lo.x, b.hi.y, b.hi.z, 1.0f));
+    r = merge(r, mat_mul_xyz(M, b.hi.x, b.hi.y, b.lo.z, 1.0f));
+    r = merge(r, mat_mul_xyz(M, b.hi.x, b.lo.y, b.hi.z, 1.0f));
+    r = merge(r, mat_mul_xyz(M, b.hi.x, b.hi.y, b.hi.z, 1.0f));
+    return r;
+}
+
+struct BuildNode {
+    Aabb box;
+    int32_t left, right;     // build-node indices, -1 for a leaf
+    int32_t start, end;
+    int32_t depth;
+};
+
+struct Task {
+    int32_t node, start, end, depth;
+};
+
+constexpr int kBins = 4;     // BVHTree.h:57
+
+}  // namespace
+
+int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err) {
+    if (!d) { err = "scene description is NULL"; return RT_ERR_INVALID; }
+    if (d->abi_version != RT_ABI_VERSION) { err = "rt_scene_desc.abi_version mismatch"; return RT_ERR_ABI; }
+    if (d->n_vertices < 0 || d->n_triangles < 0 || d->n_spheres < 0 || d->n_objects < 0 || d->n_prims < 0 || d->n_materials < 0 ||
+        d->n_lights < 0 || d->n_textures < 0) { err = "negative count in scene description"; return RT_ERR_INVALID; }
+    if (d->n_prims > RT_PRIM_INDEX_MASK || d->n_triangles > RT_PRIM_INDEX_MASK) { err = "too many primitives (limit 2^29-1)"; return RT_ERR_TOO_LARGE; }
+    if ((d->n_triangles && (!d->tri_vert || !d->tri_object || !d->vert_pos)) || (d->n_spheres && (!d->sph_center_radius || !d->sph_object)) ||
+        (d->n_objects && !d->objects) || (d->n_prims && !d->prim_shape) || (d->n_materials && !d->materials) ||
+        (d->n_lights && !d->lights) || (d->n_textures && !d->textures)) { err = "NULL array with non-zero count"; return RT_ERR_INVALID; }
+
+    // ---- tables copied as they are ---------------------------------------------------------------
+    hs.materials.assign(d->materials, d->materials + d->n_materials);
+    hs.lights.assign(d->lights, d->lights + d->n_lights);
+    hs.textures.assign(d->textures, d->textures + d->n_textures);
+    hs.texels.clear();
+    if (d->texels_bytes > 0 && d->texels) hs.texels.assign(d->texels, d->texels + d->texels_bytes);
+    for (const rt_texture &t : hs.textures) {
+        if (t.kind == RT_TEX_IMAGE) {
+            int64_t need = (int64_t)t.width * t.height * 3 * (t.texel_is_float ? 4 : 1);
+            if (t.width <= 0 || t.height <= 0 || t.texel_offset < 0 || t.texel_offset + need > (int64_t)hs.texels.size()) { err = "image texture outside the texel arena"; return RT_ERR_INVALID; }
+        } else if (t.kind == RT_TEX_PERLIN) {
+            for (int i = 0; i < 16; ++i) if (t.perm[i] < 0 || t.perm[i] > 15) { err = "perlin permutation entry out of range"; return RT_ERR_INVALID; }
+        } else { err = "unknown texture kind"; return RT_ERR_INVALID; }
+    }
+    if (d->bg_texture >= d->n_textures) { err = "bg_texture out of range"; return RT_ERR_INVALID; }
+
+    // ---- objects ---------------------------------------------------------------------------------
+    hs.objects.resize(d->n_objects);
+    for (int64_t i = 0; i < d->n_objects; ++i) {
+        const rt_object &o = d->objects[i];
+        DevObject &q = hs.objects[i];
+        if (o.material < 0 || o.material >= d->n_materials || o.tex_color >= d->n_textures || o.tex_normal >= d->n_textures) { err = "object references a missing material/texture"; return RT_ERR_INVALID; }
+        std::memcpy(q.M, o.xform, sizeof(q.M));
+        float Mt[16];
+        mat_transpose(q.M, Mt);                      // Transform::UpdateTransform, acmath.h:998-1002
+        mat_inverse(Mt, q.inv);
+        q.mblur[0] = o.motion_blur[0]; q.mblur[1] = o.motion_blur[1]; q.mblur[2] = o.motion_blur[2];
+        bool moving = o.motion_blur[0] != 0 || o.motion_blur[1] != 0 || o.motion_blur[2] != 0;   // Shape.h:111
+        q.flags = (o.flags & RT_OBJ_SMOOTH ? DEV_OBJ_SMOOTH : 0) | (o.flags & RT_OBJ_HAS_XFORM ? DEV_OBJ_HAS_XFORM : 0) |
+                  (o.flags & RT_OBJ_COMPOSITE ? DEV_OBJ_COMPOSITE : 0) | (moving ? DEV_OBJ_MOTION : 0) | (mat_is_identity(Mt) ? DEV_OBJ_IDENTITY : 0);
+        q.material = o.material; q.tex_color = o.tex_color; q.tex_normal = o.tex_normal; q._pad = 0;
+    }
+
+    // ---- triangles: edges, face normal, object box; smooth vertex normals --------------------------
+    const int64_t nT = d->n_triangles, nS = d->n_spheres;
+    std::vector<DevPrim> shapeRec(nT + nS);
+    std::vector<Aabb> shapeBox(nT + nS);
+    hs.verts.assign(d->n_vertices, DevVertex());
+    for (int64_t v = 0; v < d->n_vertices; ++v) {
+        DevVertex &dv = hs.verts[v];
+        dv.n[0] = dv.n[1] = dv.n[2] = 0.0f;
+        dv.uv[0] = d->vert_uv ? d->vert_uv[2 * v] : 0.0f;
+        dv.uv[1] = d->vert_uv ? d->vert_uv[2 * v + 1] : 0.0f;
+        dv._pad[0] = dv._pad[1] = dv._pad[2] = 0.0f;
+    }
+    hs.tri_vert.assign(d->tri_vert, d->tri_vert + 3 * nT);
+    for (int64_t t = 0; t < nT; ++t) {
+        const int32_t *iv = d->tri_vert + 3 * t;
+        int32_t ob = d->tri_object[t];
+        if (ob < 0 || ob >= d->n_objects) { err = "triangle references a missing object"; return RT_ERR_INVALID; }
+        for (int k = 0; k < 3; ++k) if (iv[k] < 0 || iv[k] >= d->n_vertices) { err = "triangle references a missing vertex"; return RT_ERR_INVALID; }
+        f3 a = ld3(d->vert_pos + 3 * iv[0]), b = ld3(d->vert_pos + 3 * iv[1]), c = ld3(d->vert_pos + 3 * iv[2]);
+        f3 ab = a - b, ac = a - c;                                   // p0p1, p0p2 (Triangle.cpp:63-64)
+        f3 fn = normalize3(cross3(-ab, -ac));                        // Triangle.cpp:66
+        DevPrim &r = shapeRec[t];
+        r.p0[0] = a.x; r.p0[1] = a.y; r.p0[2] = a.z;
+        r.e1[0] = ab.x; r.e1[1] = ab.y; r.e1[2] = ab.z;
+        r.e2[0] = ac.x; r.e2[1] = ac.y; r.e2[2] = ac.z;
+        r.nrm[0] = fn.x; r.nrm[1] = fn.y; r.nrm[2] = fn.z;
+        r.object = ob; r.shape = (int32_t)t; r.kind = DEV_PRIM_TRIANGLE; r._pad = 0;
+        shapeBox[t] = box_of(max3(a, max3(b, c)), min3(a, min3(b, c)));   // Triangle.cpp:68-69
+    }
+    {   // Mesh.cpp:88-95 + Triangle.cpp:78-105: accumulate face normals per smooth object in triangle order, then
+        // normalise every touched vertex once.
+        std::vector<std::vector<int64_t>> lists(d->n_objects);
+        for (int64_t t = 0; t < nT; ++t)
+            if (hs.objects[d->tri_object[t]].flags & DEV_OBJ_SMOOTH) lists[d->tri_object[t]].push_back(t);
+        std::vector<uint8_t> pending(d->n_vertices, 0);
+        for (const auto &list : lists) {
+            for (int64_t t : list)
+                for (int k = 0; k < 3; ++k) {
+                    DevVertex &dv = hs.verts[d->tri_vert[3 * t + k]];
+                    dv.n[0] += shapeRec[t].nrm[0]; dv.n[1] += shapeRec[t].nrm[1]; dv.n[2] += shapeRec[t].nrm[2];
+                    pending[d->tri_vert[3 * t + k]] = 1;
+                }
+            for (int64_t t : list)
+                for (int k = 0; k < 3; ++k) {
+                    int32_t vi = d->tri_vert[3 * t + k];
+                    if (!pending[vi]) continue;
+                    f3 n = normalize3(ld3(hs.verts[vi].n));
+                    hs.verts[vi].n[0] = n.x; hs.verts[vi].n[1] = n.y; hs.verts[vi].n[2] = n.z;
+                    pending[vi] = 0;
+                }
+        }
+    }
+    for (int64_t s = 0; s < nS; ++s) {                                   // Sphere.cpp:9-21
+        int32_t ob = d->sph_object[s];
+        if (ob < 0 || ob >= d->n_objects) { err = "sphere references a missing object"; return RT_ERR_INVALID; }
+        f3 c = ld3(d->sph_center_radius + 4 * s);
+        float rad = d->sph_center_radius[4 * s + 3];
+        DevPrim &r = shapeRec[nT + s];
+        std::memset(&r, 0, sizeof(r));
+        r.p0[0] = c.x; r.p0[1] = c.y; r.p0[2] = c.z; r.e1[0] = rad;
+        r.object = ob; r.shape = (int32_t)s | RT_PRIM_SPHERE; r.kind = DEV_PRIM_SPHERE;
+        shapeBox[nT + s] = box_of(c + mk3(-rad, -rad, -rad), c + mk3(rad, rad, rad));
+    }
+
+    // ---- reference primitives and their world boxes (Q5, Q29) -------------------------------------
+    const int64_t nP = d->n_prims;
+    std::vector<Aabb> pbox(nP);
+    std::vector<int32_t> pshape(nP);           // index into shapeRec
+    for (int64_t i = 0; i < nP; ++i) {
+        int32_t ref = d->prim_shape[i];
+        int64_t idx = ref & RT_PRIM_INDEX_MASK;
+        bool sph = (ref & RT_PRIM_SPHERE) != 0;
+        if (idx >= (sph ? nS : nT)) { err = "primitive references a missing shape"; return RT_ERR_INVALID; }
+        int64_t si = sph ? nT + idx : idx;
+        const DevObject &ob = hs.objects[shapeRec[si].object];
+        Aabb wb = (ob.flags & DEV_OBJ_HAS_XFORM) ? transform_box(ob.M, shapeBox[si]) : shapeBox[si];
+        if ((ref & RT_PRIM_BLURBOX) && (ob.flags & DEV_OBJ_MOTION)) {   // Shape::AdaptWorldBoundingBoxForMotionBlur
+            float moved[16];
+            mat_translate_mul(ld3(ob.mblur), ob.M, moved);
+            wb = merge(wb, transform_box(moved, shapeBox[si]));
+        }
+        pbox[i] = wb;
+        pshape[i] = (int32_t)si;
+    }
+
+    // ---- BVH build (BVHTree.cpp:39-153), explicit work stack, nodes created in preorder ------------
+    std::vector<int32_t> order(nP);
+    for (int64_t i = 0; i < nP; ++i) order[i] = (int32_t)i;
+    std::vector<BuildNode> bn;
+    int maxDepth = 0;
+    if (nP > 0) {
+        bn.reserve((size_t)nP);
+        std::vector<Task> work;
+        bn.push_back(BuildNode());
+        work.push_back(Task{0, 0, (int32_t)nP, 1});
+        while (!work.empty()) {
+            Task tk = work.back();
+            work.pop_back();
+            maxDepth = std::max(maxDepth, tk.depth);
+            const int count = tk.end - tk.start;
+            bn[tk.node].start = tk.start; bn[tk.node].end = tk.end; bn[tk.node].left = bn[tk.node].right = -1; bn[tk.node].depth = tk.depth;
+            if (count <= 1) { bn[tk.node].box = pbox[order[tk.start]]; continue; }
+            Aabb all = empty_box(), cen = empty_box();
+            for (int i = tk.start; i < tk.end; ++i) {
+                all = merge(all, pbox[order[i]]);
+                cen = merge(cen, centroid(pbox[order[i]]));
+            }
+            const int ax = widest_axis(cen.hi - cen.lo);
+            const float clo = comp3(cen.lo, ax), chi = comp3(cen.hi, ax);
+            if (std::abs(chi - clo) < 0.00000001f) { bn[tk.node].box = all; continue; }
+            int binCount[kBins] = {0, 0, 0, 0};
+            Aabb binBox[kBins] = {empty_box(), empty_box(), empty_box(), empty_box()};
+            for (int i = tk.start; i < tk.end; ++i) {
+                float cp = (comp3(centroid(pbox[order[i]]), ax) - clo) / (chi - clo);     // ClippedPosition acmath.h:942
+                int bin = kBins * cp;
+                if (bin == kBins) --bin;
+                binCount[bin]++;
+                binBox[bin] = merge(binBox[bin], pbox[order[i]]);
+            }
+            int fwdCount[kBins], bwdCount[kBins];
+            Aabb fwdBox[kBins], bwdBox[kBins];
+            fwdCount[0] = binCount[0]; fwdBox[0] = binBox[0];
+            for (int i = 1; i < kBins; ++i) { fwdBox[i] = merge(binBox[i], fwdBox[i - 1]); fwdCount[i] = binCount[i] + fwdCount[i - 1]; }
+            bwdCount[kBins - 1] = binCount[kBins - 1]; bwdBox[kBins - 1] = binBox[kBins - 1];
+            float cost[kBins];
+            const float saAll = surface_area(all);
+            cost[kBins - 1] = 0.125f + (fwdCount[kBins - 1] * surface_area(fwdBox[kBins - 1])) / saAll;
+            for (int i = kBins - 2; i >= 0; --i) {
+                bwdBox[i] = merge(binBox[i], bwdBox[i + 1]); bwdCount[i] = binCount[i] + bwdCount[i + 1];
+                cost[i] = 0.125f + (fwdCount[i] * surface_area(fwdBox[i]) + bwdCount[i + 1] * surface_area(bwdBox[i + 1])) / saAll;
+            }
+            float best = 1e9;
+            int split = -1;
+            for (int i = 0; i < kBins; ++i) if (best > cost[i]) { best = cost[i]; split = i; }
+            if (!(best < count)) { bn[tk.node].box = all; continue; }
+            int32_t *mid = std::partition(&order[tk.start], &order[tk.end - 1] + 1, [&](int32_t p) {
+                int in = kBins * ((comp3(centroid(pbox[p]), ax) - clo) / (chi - clo));
+                return in <= split;
+            });
+            const int32_t m = (int32_t)(mid - &order[0]);
+            const int32_t l = (int32_t)bn.size();
+            bn.push_back(BuildNode());
+            bn.push_back(BuildNode());
+            bn[tk.node].left = l; bn[tk.node].right = l + 1;
+            work.push_back(Task{l + 1, m, tk.end, tk.depth + 1});     // right is built after the whole left subtree
+            work.push_back(Task{l, tk.start, m, tk.depth + 1});
+        }
+        for (int64_t i = (int64_t)bn.size() - 1; i >= 0; --i)          // BuildInternal: box = Merge(left, right)
+            if (bn[i].left >= 0) bn[i].box = merge(bn[bn[i].left].box, bn[bn[i].right].box);
+    }
+
+    // ---- flatten ------------------------------------------------------------------------------------
+    hs.nodes.clear(); hs.leaves.clear(); hs.prims.clear(); hs.ref_leaf_range.clear(); hs.leaf_boxes.clear();
+    hs.ref_prim_order.resize(nP);
+    for (int64_t i = 0; i < nP; ++i) hs.ref_prim_order[i] = shapeRec[pshape[order[i]]].shape;
+    std::memset(&hs.params, 0, sizeof(hs.params));
+    hs.params.root = RT_NO_ROOT;
+    auto store3 = [](float *dst, f3 v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; };
+    if (!bn.empty()) {
+        // preorder numbering of internal nodes; DFS numbering of leaves
+        std::vector<int32_t> ref(bn.size(), 0);
+        std::vector<int32_t> stack;
+        stack.push_back(0);
+        std::vector<int32_t> internalOrder;
+        while (!stack.empty()) {
+            int32_t n = stack.back();
+            stack.pop_back();
+            if (bn[n].left < 0) {
+                DevLeaf lf;
+                lf.start = (int32_t)hs.prims.size();
+                for (int i = bn[n].start; i < bn[n].end; ++i) {
+                    const DevPrim &rec = shapeRec[pshape[order[i]]];
+                    bool dup = false;      // a second reference to the same shape inside one leaf can never win
+                    for (size_t k = lf.start; k < hs.prims.size() && !dup; ++k) dup = hs.prims[k].shape == rec.shape;
+                    if (!dup) hs.prims.push_back(rec);
+                }
+                lf.count = (int32_t)hs.prims.size() - lf.start;
+                ref[n] = ~(int32_t)hs.leaves.size();
+                hs.leaves.push_back(lf);
+                hs.ref_leaf_range.push_back(bn[n].start); hs.ref_leaf_range.push_back(bn[n].end);
+                const Aabb &b = bn[n].box;
+                const float bb[6] = {b.lo.x, b.lo.y, b.lo.z, b.hi.x, b.hi.y, b.hi.z};
+                hs.leaf_boxes.insert(hs.leaf_boxes.end(), bb, bb + 6);
+            } else {
+                ref[n] = (int32_t)internalOrder.size();
+                internalOrder.push_back(n);
+                stack.push_back(bn[n].right);
+                stack.push_back(bn[n].left);
+            }
+        }
+        hs.nodes.resize(internalOrder.size());
+        for (size_t k = 0; k < internalOrder.size(); ++k) {
+            const BuildNode &b = bn[internalOrder[k]];
+            DevNode &dn = hs.nodes[k];
+            store3(dn.lmin, bn[b.left].box.lo); store3(dn.lmax, bn[b.left].box.hi);
+            store3(dn.rmin, bn[b.right].box.lo); store3(dn.rmax, bn[b.right].box.hi);
+            dn.left = ref[b.left]; dn.right = ref[b.right]; dn._pad[0] = dn._pad[1] = 0;
+        }
+        hs.params.root = ref[0];
+        store3(hs.params.root_min, bn[0].box.lo); store3(hs.params.root_max, bn[0].box.hi);
+    }
+    hs.params.max_depth = d->max_depth; hs.params.isect_eps = d->isect_eps; hs.params.shadow_eps = d->shadow_eps;
+    for (int k = 0; k < 3; ++k) { hs.params.background[k] = d->background[k]; hs.params.ambient[k] = d->ambient[k]; }
+    hs.params.bg_texture = d->bg_texture;
+    hs.params.n_lights = d->n_lights; hs.params.n_materials = d->n_materials; hs.params.n_textures = d->n_textures;
+    hs.params.bvh_depth = maxDepth;
+    float scale = 1.0f;
+    if (!bn.empty())
+        for (int k = 0; k < 3; ++k) scale = std::max(scale, std::max(std::fabs(hs.params.root_min[k]), std::fabs(hs.params.root_max[k])));
+    hs.scene_scale = scale;
+    hs.params.prune_err = 2e-4f * scale;
+    hs.info.n_nodes = (int64_t)bn.size(); hs.info.n_leaves = (int64_t)hs.leaves.size(); hs.info.max_depth = maxDepth; hs.info._pad = 0;
+    hs.info.n_leaf_prims = (int64_t)hs.prims.size();
+    return RT_OK;
+}

@@ -1,0 +1,90 @@
+// rt_device.h — HBM data layout shared by the host flattener (rt_build.cpp) and the gfx950 kernels.
+//
+// Everything the traversal touches is a 64-byte record (one 128-B HBM request carries two of them, one
+// L2 line exactly one):
+//   DevNode  — one per INTERNAL node; holds BOTH child boxes so one fetch decides both descents
+//   DevPrim  — one per leaf primitive reference, stored in leaf order (a leaf is a contiguous run)
+// Leaves are not nodes: a child reference < 0 is ~leafIndex into DevLeaf[] and leafIndex is the leaf's
+// position in the reference tree's left-to-right DFS order, which is the tie-break key of Q4.
+#ifndef RT_DEVICE_H_
+#define RT_DEVICE_H_
+
+#include <stdint.h>
+
+#include "../../include/rt_mi355.h"
+
+struct alignas(64) DevNode {
+    float lmin[3], lmax[3];   // left child box   (BVHNode::bbox of left,  reference src/BVHTree.h:20)
+    float rmin[3], rmax[3];   // right child box
+    int32_t left, right;      // >= 0: internal node index, < 0: ~leafIndex
+    int32_t _pad[2];
+};
+static_assert(sizeof(DevNode) == 64, "DevNode must be 64 bytes");
+
+struct DevLeaf {
+    int32_t start, count;     // run inside DevPrim[]
+};
+
+enum { DEV_PRIM_TRIANGLE = 0, DEV_PRIM_SPHERE = 1 };
+
+struct alignas(64) DevPrim {
+    float p0[3];              // triangle: v0 position            | sphere: centre
+    float e1[3];              // triangle: p0p1 = p0 - p1         | sphere: radius, 0, 0
+    float e2[3];              // triangle: p0p2 = p0 - p2
+    float nrm[3];             // triangle: object-space unit normal (Triangle.cpp:37)
+    int32_t object;           // DevObject index (transform, material, textures, container identity)
+    int32_t shape;            // rt_hit.shape id: triangle index, or sphere index | RT_PRIM_SPHERE
+    int32_t kind;             // DEV_PRIM_*
+    int32_t _pad;
+};
+static_assert(sizeof(DevPrim) == 64, "DevPrim must be 64 bytes");
+
+enum { DEV_OBJ_SMOOTH = 1, DEV_OBJ_HAS_XFORM = 2, DEV_OBJ_COMPOSITE = 4, DEV_OBJ_MOTION = 8, DEV_OBJ_IDENTITY = 16 };
+
+// 160 bytes; matrices in glm order m[col*4+row].
+struct alignas(16) DevObject {
+    float M[16];              // Transform::transposeMatrix        (object -> world)
+    float inv[16];            // Transform::invTransformationMatrix = inverse(transpose(M))
+    float mblur[3];
+    int32_t flags;            // DEV_OBJ_*
+    int32_t material, tex_color, tex_normal, _pad;
+};
+static_assert(sizeof(DevObject) == 160, "DevObject must be 160 bytes");
+
+struct DevVertex {            // 32 bytes: what the winner's finalisation reads
+    float n[3];               // smooth-shading vertex normal (Q28)
+    float uv[2];
+    float _pad[3];
+};
+static_assert(sizeof(DevVertex) == 32, "DevVertex must be 32 bytes");
+
+struct DevSceneParams {
+    int32_t max_depth;
+    float isect_eps, shadow_eps;
+    float background[3];
+    float ambient[3];
+    int32_t bg_texture;
+    int32_t n_lights, n_materials, n_textures;
+    int32_t root;             // >= 0 internal node index, < 0 ~leafIndex, RT_NO_ROOT when the scene is empty
+    float root_min[3], root_max[3];
+    float prune_err;          // absolute bound used to keep t-pruning conservative
+    int32_t bvh_depth;
+};
+#define RT_NO_ROOT 0x7fffffff
+
+// Pointers to the uploaded scene (all device memory).
+struct DevScene {
+    DevSceneParams p;
+    const DevNode *nodes;
+    const DevLeaf *leaves;
+    const DevPrim *prims;
+    const DevObject *objects;
+    const DevVertex *verts;
+    const int32_t *tri_vert;      // [n_triangles][3]
+    const rt_material *materials;
+    const rt_light *lights;
+    const rt_texture *textures;
+    const uint8_t *texels;
+};
+
+#endif

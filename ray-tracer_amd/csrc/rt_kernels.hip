@@ -1,0 +1,1004 @@
+// rt_kernels.hip — gfx950 (MI355X, CDNA4) kernels of the render hot path.
+//
+//   k_raygen       Camera::GenerateRay / GenerateRayForPixelSample, JitteredPixelSampler, MultiSampledRayGenerator
+//                  (src/Camera.cpp:76-147, src/PixelSampler.cpp:27-38, src/MultiSampledRayGenerator.cpp:25-33)
+//   k_trace*       BVHTree::Intersect and everything under it (src/BVHTree.cpp:155-206, src/acmath.h:770-820,
+//                  src/Triangle.cpp:115-302, src/Sphere.cpp:31-131, src/Shape.cpp:67-82)
+//   k_shade_pre    normal tweak + shadow-ray generation (src/Intersection.cpp:25-29, src/LightContributionCalculator.cpp:114-145,
+//                  src/Light.cpp:89-129)
+//   k_shade_post   lights, BRDFs, Fresnel, child-ray generation with wave64 ballot compaction
+//                  (src/LightContributionCalculator.cpp:46-124, src/Light.cpp:37-87, src/brdf.cpp, src/Material.cpp,
+//                  src/RecursiveComputation.cpp:8-228)
+//   k_backward     the "+=" side of RecursiveComputation::Perform{Reflection,Refraction}/AddDielectricConsumption
+//   k_resolve      RenderMultiSampled's mean (src/DefaultRenderer.cpp:106-138)
+//
+// No MFMA anywhere: the path is pointer-chasing + scalar-per-lane float math, bound by L2/HBM latency and VALU issue.
+// Wave64 throughout; the traversal stack lives in LDS (one 4-byte column per lane, bank == lane, conflict-free).
+#include <float.h>
+
+#include "rt_math.h"
+#include "rt_wavefront.h"
+
+#define TRACE_BLOCK 256
+#define LDS_STACK 24
+#define TRACE_BLOCKS_PER_CU 6
+#define NUM_CUS 256
+
+int rt_trace_grid_threads() { return NUM_CUS * TRACE_BLOCKS_PER_CU * TRACE_BLOCK; }
+int rt_trace_lds_stack_depth() { return LDS_STACK; }
+
+// ====================================================================================================
+// Counter-based RNG: Philox4x32-10, key = (seed, pixel), counter = (sample, path, slot, 0).
+// ====================================================================================================
+enum { SLOT_PIXEL = 0, SLOT_TIME = 1, SLOT_GLOSSY = 2, SLOT_LIGHT0 = 3 };
+
+__device__ __forceinline__ void philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// the four 24-bit uniforms of one slot, as doubles in [0,1)
+__device__ __forceinline__ void rng_slot(unsigned seed, unsigned pixel, unsigned sample, unsigned path, unsigned slot, double u[4]) {
+    unsigned w[4];
+    philox4x32(sample, path, slot, 0u, seed, pixel, w);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = (double)(w[i] >> 8) * (1.0 / 16777216.0);
+}
+// std::uniform_real_distribution<double>(a,b): u*(b-a)+a
+__device__ __forceinline__ double uni(double u, double a, double b) { return u * (b - a) + a; }
+
+// ====================================================================================================
+// Traversal
+// ====================================================================================================
+struct Cand {
+    float t;       // x-only world parameter (Q2)
+    f3 ip;         // world intersection point
+    float beta, gamma;
+    int prim;      // DevPrim record index, -1 = none
+};
+
+struct ObjXf {     // per-lane cache of "the ray in the space of object `id`" (Q8: identical for all triangles of a mesh)
+    int id;
+    int flags;     // DEV_OBJ_* of the object, DEV_OBJ_IDENTITY re-evaluated for motion-blurred objects
+    f3 o, d;       // object-space ray
+    float M[12];   // xyz rows of the 4 columns of the object->world matrix in effect (T(blur*time)*M for moving objects)
+};
+
+__device__ __forceinline__ f3 obj_to_world_point(const float *M12, f3 p) {   // glm mat*vec4(p,1): (m0*x + m1*y) + (m2*z + m3*1)
+    f3 r;
+    r.x = (M12[0] * p.x + M12[3] * p.y) + (M12[6] * p.z + M12[9] * 1.0f);
+    r.y = (M12[1] * p.x + M12[4] * p.y) + (M12[7] * p.z + M12[10] * 1.0f);
+    r.z = (M12[2] * p.x + M12[5] * p.y) + (M12[8] * p.z + M12[11] * 1.0f);
+    return r;
+}
+
+// Matrices in effect for `ob` at ray time: M (object->world) and inv = inverse(transpose(M)).
+__device__ __forceinline__ void object_matrices(const DevObject &ob, float time, float *M, float *inv, int &flags) {
+    flags = ob.flags;
+    if (ob.flags & DEV_OBJ_MOTION) {                                  // Shape.cpp:71-79, Triangle.cpp:168-175
+        f3 mv = ld3(ob.mblur) * time;
+        mat_translate_mul(mv, ob.M, M);
+        float Mt[16];
+        mat_transpose(M, Mt);
+        mat_inverse(Mt, inv);
+        flags = (flags & ~DEV_OBJ_IDENTITY) | (mat_is_identity(Mt) ? DEV_OBJ_IDENTITY : 0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { M[i] = ob.M[i]; inv[i] = ob.inv[i]; }
+    }
+}
+
+__device__ __noinline__ void enter_object(const DevScene &sc, int obj, f3 o, f3 d, float time, ObjXf &x) {
+    const DevObject &ob = sc.objects[obj];
+    x.id = obj;
+    if (!(ob.flags & DEV_OBJ_HAS_XFORM)) {                            // standalone <Triangle>: objTransform == nullptr (Shape.cpp:69)
+        x.flags = ob.flags | DEV_OBJ_IDENTITY;
+        x.o = o; x.d = d;
+        return;
+    }
+    float M[16], inv[16];
+    object_matrices(ob, time, M, inv, x.flags);
+    // Transform::operator()(Ray, obj2world=false): transpose(inv) * (o,1), transpose(inv) * (d,0), renormalise (acmath.h:1053-1069)
+    x.o = matT_mul_xyz(inv, o.x, o.y, o.z, 1.0f);
+    x.d = normalize3(matT_mul_xyz(inv, d.x, d.y, d.z, 0.0f));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { x.M[c * 3 + 0] = M[c * 4 + 0]; x.M[c * 3 + 1] = M[c * 4 + 1]; x.M[c * 3 + 2] = M[c * 4 + 2]; }
+}
+
+__device__ __forceinline__ float det3(float ax, float ay, float az, float bx, float by, float bz, float cx, float cy, float cz) {
+    // r1=(ax,ay,az) r2=(bx,by,bz) r3=(cx,cy,cz); Triangle.cpp:197 association
+    return ax * (by * cz - bz * cy) + bx * (az * cy - ay * cz) + cx * (ay * bz - az * by);
+}
+
+// Triangle::Intersect up to the world-space t (Triangle.cpp:115-135, 186-250; Q2, Q6, Q8)
+__device__ __forceinline__ bool hit_triangle(const float4 q0, const float4 q1, const float4 q2, const ObjXf &x, f3 wo, f3 wd, float eps, Cand &c) {
+    const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
+    const f3 d = x.d;
+    const f3 pr = mk3(p0.x - x.o.x, p0.y - x.o.y, p0.z - x.o.z);
+    const float detM = det3(e1.x, e2.x, d.x, e1.y, e2.y, d.y, e1.z, e2.z, d.z);
+    if (detM == 0.0f) return false;
+    const float inv = 1 / detM;
+    const float beta = det3(pr.x, e2.x, d.x, pr.y, e2.y, d.y, pr.z, e2.z, d.z) * inv;
+    const float err = 1 + eps;
+    if (beta < -eps || beta > err) return false;
+    const float gamma = det3(e1.x, pr.x, d.x, e1.y, pr.y, d.y, e1.z, pr.z, d.z) * inv;
+    if (gamma < -eps || gamma > err || beta + gamma > err) return false;
+    const float t = det3(e1.x, e2.x, pr.x, e1.y, e2.y, pr.y, e1.z, e2.z, pr.z) * inv;
+    if (!(t >= -eps)) return false;
+    f3 ip = x.o + d * t;
+    if (!(x.flags & DEV_OBJ_IDENTITY)) ip = obj_to_world_point(x.M, ip);      // Triangle.cpp:296-298
+    c.t = (ip.x - wo.x) / wd.x;                                                // Ray::operator()(Vector3f), acmath.h:742
+    c.ip = ip; c.beta = beta; c.gamma = gamma;
+    return true;
+}
+
+// Sphere::CalculateTValueForIntersection (Sphere.cpp:61-91): object-space t or "no hit"
+__device__ __forceinline__ bool sphere_t(f3 center, float radius, f3 o, f3 d, float &t) {
+    f3 oc = o - center;
+    float b = dot3(oc, d);
+    float dd = dot3(d, d);
+    float disc = b * b - dd * (dot3(oc, oc) - radius * radius);
+    if (disc < 0) return false;
+    disc = sqrtf(disc);
+    t = -1 * b - disc;
+    if (t < 0 || ((-b + disc) < t && -b + disc > 0)) t = -1 * b + disc;
+    t /= dd;
+    return t > 0;
+}
+__device__ __forceinline__ bool hit_sphere(const float4 q0, const ObjXf &x, f3 wo, f3 wd, Cand &c) {
+    float t;
+    if (!sphere_t(mk3(q0.x, q0.y, q0.z), q0.w, x.o, x.d, t)) return false;
+    f3 ip = obj_to_world_point(x.M, x.o + x.d * t);                           // Sphere.cpp:128 (no identity shortcut, Q9)
+    c.t = (ip.x - wo.x) / wd.x;
+    c.ip = ip; c.beta = 0; c.gamma = 0;
+    return true;
+}
+
+// BoundingVolume3::Intersect (acmath.h:770-820, Q3) for one box, plus a conservative lower bound `lb` on the x-only t
+// of anything that can be hit inside the box (see DESIGN.md "pruning").
+__device__ __forceinline__ bool slab(f3 bmin, f3 bmax, f3 o, f3 d, f3 marg, float &tn_out, float &lb_out) {
+    float tn = 0, tf = FLT_MAX, lb;
+    float a = (bmin.x - o.x) / d.x, b = (bmax.x - o.x) / d.x;
+    if (a > b) { float s = a; a = b; b = s; }
+    tn = sel_max(tn, a); tf = sel_min(tf, b);
+    lb = a - marg.x;
+    a = (bmin.y - o.y) / d.y; b = (bmax.y - o.y) / d.y;
+    if (a > b) { float s = a; a = b; b = s; }
+    tn = sel_max(tn, a); tf = sel_min(tf, b);
+    lb = sel_max(lb, a - marg.y);
+    a = (bmin.z - o.z) / d.z; b = (bmax.z - o.z) / d.z;
+    if (a > b) { float s = a; a = b; b = s; }
+    tn = sel_max(tn, a); tf = sel_min(tf, b);
+    lb = sel_max(lb, a - marg.z);
+    lb = lb - marg.x;
+    lb = lb - fabsf(lb) * 1e-6f;
+    tn_out = tn; lb_out = lb;
+    return !(tf < tn);
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void trace_closest(const DevScene &sc, f3 o, f3 d, float time, int *lds_col, int *ovf_col, int ovf_stride,
+                                              Cand &best, int &best_leaf, unsigned &cnt_nodes, unsigned &cnt_boxes, unsigned &cnt_tris, unsigned &cnt_sph) {
+    best.t = FLT_MAX; best.prim = -1; best.ip = mk3(0, 0, 0); best.beta = best.gamma = 0;
+    best_leaf = -1;
+    if (sc.p.root == RT_NO_ROOT) return;
+    const float eps = sc.p.isect_eps;
+    const float err = sc.p.prune_err + 1e-3f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z)) * 0.2f;
+    const f3 marg = mk3(err / fabsf(d.x), err / fabsf(d.y), err / fabsf(d.z));
+    {
+        float tn, lb;
+        if (COUNT) ++cnt_boxes;
+        if (!slab(ld3(sc.p.root_min), ld3(sc.p.root_max), o, d, marg, tn, lb)) return;
+    }
+    const float4 *nodes4 = reinterpret_cast<const float4 *>(sc.nodes);
+    const float4 *prims4 = reinterpret_cast<const float4 *>(sc.prims);
+    ObjXf xf;
+    xf.id = -2; xf.flags = 0; xf.o = o; xf.d = d;
+    int sp = 0;
+    int cur = sc.p.root;
+    for (;;) {
+        if (cur >= 0) {
+            const float4 n0 = nodes4[cur * 4 + 0], n1 = nodes4[cur * 4 + 1], n2 = nodes4[cur * 4 + 2], n3 = nodes4[cur * 4 + 3];
+            float tnl, tnr, lbl, lbr;
+            bool hl = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, d, marg, tnl, lbl);
+            bool hr = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, d, marg, tnr, lbr);
+            if (COUNT) { ++cnt_nodes; cnt_boxes += 2; }
+            hl = hl && !(lbl > best.t);
+            hr = hr && !(lbr > best.t);
+            const int left = __float_as_int(n3.x), right = __float_as_int(n3.y);
+            if (hl && hr) {
+                int nearc = left, farc = right;
+                if (tnr < tnl) { nearc = right; farc = left; }
+                if (sp < LDS_STACK) lds_col[sp * TRACE_BLOCK] = farc; else ovf_col[(sp - LDS_STACK) * ovf_stride] = farc;
+                ++sp;
+                cur = nearc;
+                continue;
+            } else if (hl) { cur = left; continue; }
+            else if (hr) { cur = right; continue; }
+        } else {
+            // ProcessIntersectionForLeafNode (BVHTree.cpp:177-190): fresh result, array order, accept t>0 && t < best-0.001
+            const int leaf = ~cur;
+            const DevLeaf lf = sc.leaves[leaf];
+            Cand local;
+            local.t = FLT_MAX; local.prim = -1; local.ip = mk3(0, 0, 0); local.beta = local.gamma = 0;
+            for (int i = lf.start; i < lf.start + lf.count; ++i) {
+                const float4 q0 = prims4[i * 4 + 0], q3 = prims4[i * 4 + 3];
+                const int obj = __float_as_int(q3.x), kind = __float_as_int(q3.z);
+                if (obj != xf.id) enter_object(sc, obj, o, d, time, xf);
+                Cand c;
+                bool ok;
+                if (kind == DEV_PRIM_TRIANGLE) {
+                    const float4 q1 = prims4[i * 4 + 1], q2 = prims4[i * 4 + 2];
+                    if (COUNT) ++cnt_tris;
+                    ok = hit_triangle(q0, q1, q2, xf, o, d, eps, c);
+                } else {
+                    if (COUNT) ++cnt_sph;
+                    ok = hit_sphere(q0, xf, o, d, c);
+                }
+                if (ok && c.t > 0 && c.t < local.t - 0.001f) { local = c; local.prim = i; }
+            }
+            // ProcessIntersectionForInternalNode (BVHTree.cpp:192-206) reduced over all leaves: smaller t wins, ties go
+            // to the leaf that comes later in DFS order (Q4)
+            if (local.prim >= 0 && (local.t < best.t || (local.t == best.t && leaf > best_leaf))) { best = local; best_leaf = leaf; }
+        }
+        if (sp == 0) break;
+        --sp;
+        cur = (sp < LDS_STACK) ? lds_col[sp * TRACE_BLOCK] : ovf_col[(sp - LDS_STACK) * ovf_stride];
+    }
+}
+
+struct HitOut {
+    float t; int shape, object, prim;
+    f3 ip, n; float u, v, theta, phi;
+};
+
+// What Triangle::Intersect / Sphere::Intersect put into the SurfaceIntersection of the winning primitive.
+__device__ __noinline__ void finalize_hit(const DevScene &sc, f3 o, f3 d, float time, const Cand &best, HitOut &h) {
+    h.t = best.t; h.prim = best.prim; h.ip = best.ip; h.theta = h.phi = 0; h.u = h.v = 0; h.n = mk3(0, 0, 0);
+    if (best.prim < 0) { h.shape = -1; h.object = -1; h.t = FLT_MAX; return; }
+    const DevPrim &P = sc.prims[best.prim];
+    const DevObject &ob = sc.objects[P.object];
+    h.shape = P.shape; h.object = P.object;
+    float M[16], inv[16];
+    int flags = ob.flags | ((ob.flags & DEV_OBJ_HAS_XFORM) ? 0 : DEV_OBJ_IDENTITY);
+    if (ob.flags & DEV_OBJ_HAS_XFORM) object_matrices(ob, time, M, inv, flags);
+    if (P.kind == DEV_PRIM_TRIANGLE) {
+        const float eps = sc.p.isect_eps;
+        const int *tv = sc.tri_vert + 3 * (size_t)P.shape;
+        const DevVertex &a = sc.verts[tv[0]], &b = sc.verts[tv[1]], &c = sc.verts[tv[2]];
+        const float e = 1 + eps;
+        const float w0 = e - best.beta - best.gamma;                           // Triangle.cpp:252-266
+        h.u = a.uv[0] * w0 + b.uv[0] * best.beta + c.uv[0] * best.gamma;
+        h.v = a.uv[1] * w0 + b.uv[1] * best.beta + c.uv[1] * best.gamma;
+        f3 n = ld3(P.nrm);
+        if (ob.flags & DEV_OBJ_SMOOTH) n = normalize3(ld3(a.n) * w0 + ld3(b.n) * best.beta + ld3(c.n) * best.gamma);
+        if (!(flags & DEV_OBJ_IDENTITY)) n = normalize3(mat_mul_xyz(inv, n.x, n.y, n.z, 0.0f));   // Triangle.cpp:299-300
+        h.n = n;
+    } else {
+        // Sphere.cpp:31-54, 98-131 re-evaluated for the winner (deterministic: same values as during traversal)
+        const f3 center = ld3(P.p0);
+        const float radius = P.e1[0];
+        f3 so = matT_mul_xyz(inv, o.x, o.y, o.z, 1.0f), sd = normalize3(matT_mul_xyz(inv, d.x, d.y, d.z, 0.0f));
+        float t = 0;
+        sphere_t(center, radius, so, sd, t);
+        f3 p = so + sd * t;
+        f3 n = (p - center) / radius;
+        float theta = acosf((p.y - center.y) / radius);
+        float phi = atan2f((p.z - center.z), (p.x - center.x));
+        const double PI = 3.14159265;
+        h.u = (float)((-phi + PI) / (2 * PI));
+        h.v = (float)(theta / PI);
+        h.theta = (float)(h.v * PI);
+        h.phi = (float)(PI - (2 * PI) * h.u);
+        h.n = normalize3(mat_mul_xyz(inv, n.x, n.y, n.z, 0.0f));
+    }
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void flush_counters(DevCounters *counters, unsigned n, unsigned b, unsigned t, unsigned s) {
+    if (!COUNT || !counters) return;
+    // wave64 reduction, one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        n += __shfl_down(n, off); b += __shfl_down(b, off); t += __shfl_down(t, off); s += __shfl_down(s, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&counters->node_visits, (unsigned long long)n); atomicAdd(&counters->box_tests, (unsigned long long)b);
+        atomicAdd(&counters->tri_tests, (unsigned long long)t); atomicAdd(&counters->sphere_tests, (unsigned long long)s);
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace(DevScene sc, LevelBuf lv, int n, int *ovf, int ovf_stride, DevCounters *counters) {
+    __shared__ int s_stack[LDS_STACK * TRACE_BLOCK];
+    const int gtid = blockIdx.x * TRACE_BLOCK + threadIdx.x;
+    const int nthreads = gridDim.x * TRACE_BLOCK;
+    unsigned cn = 0, cb = 0, ct = 0, cs = 0;
+    for (int i = gtid; i < n; i += nthreads) {
+        const float4 ro = lv.ray_o[i], rd = lv.ray_d[i];
+        const f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
+        Cand best; int leaf;
+        trace_closest<COUNT>(sc, o, d, ro.w, s_stack + threadIdx.x, ovf + gtid, ovf_stride, best, leaf, cn, cb, ct, cs);
+        HitOut h;
+        finalize_hit(sc, o, d, ro.w, best, h);
+        lv.hit0[i] = make_float4(h.t, __int_as_float(h.shape), __int_as_float(h.object), __int_as_float(h.prim));
+        lv.hit1[i] = make_float4(h.ip.x, h.ip.y, h.ip.z, h.n.x);
+        lv.hit2[i] = make_float4(h.n.y, h.n.z, h.u, h.v);
+        lv.hit3[i] = make_float4(h.theta, h.phi, 0.0f, 0.0f);
+    }
+    flush_counters<COUNT>(counters, cn, cb, ct, cs);
+}
+
+// Shadow rays (Q7): a full closest-hit query, then the distance window test of
+// LightContributionCalculator::IsThereAnObjectBetweenLightAndIntersectionPoint (:130-145).
+template <bool COUNT>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow(DevScene sc, ShadowBuf sb, int n, int *ovf, int ovf_stride, DevCounters *counters) {
+    __shared__ int s_stack[LDS_STACK * TRACE_BLOCK];
+    const int gtid = blockIdx.x * TRACE_BLOCK + threadIdx.x;
+    const int nthreads = gridDim.x * TRACE_BLOCK;
+    unsigned cn = 0, cb = 0, ct = 0, cs = 0;
+    for (int i = gtid; i < n; i += nthreads) {
+        const float4 ref = sb.ipref[i];
+        if (ref.w == 0.0f) { sb.occluded[i] = 0; continue; }
+        const float4 ro = sb.o[i], rd = sb.d[i];
+        const f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
+        Cand best; int leaf;
+        trace_closest<COUNT>(sc, o, d, ro.w, s_stack + threadIdx.x, ovf + gtid, ovf_stride, best, leaf, cn, cb, ct, cs);
+        int occ = 0;
+        if (best.prim >= 0) {
+            const float dist = norm3(best.ip - mk3(ref.x, ref.y, ref.z));
+            const float se = sc.p.shadow_eps;
+            occ = (dist > se && dist < rd.w - se) ? 1 : 0;
+        }
+        sb.occluded[i] = occ;
+    }
+    flush_counters<COUNT>(counters, cn, cb, ct, cs);
+}
+
+// rt_intersect_batch: AccelerationStructure::Intersect for n independent rays
+template <bool COUNT>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_batch(DevScene sc, const rt_ray *rays, rt_hit *hits, int n, int *ovf, int ovf_stride, DevCounters *counters) {
+    __shared__ int s_stack[LDS_STACK * TRACE_BLOCK];
+    const int gtid = blockIdx.x * TRACE_BLOCK + threadIdx.x;
+    const int nthreads = gridDim.x * TRACE_BLOCK;
+    unsigned cn = 0, cb = 0, ct = 0, cs = 0;
+    for (int i = gtid; i < n; i += nthreads) {
+        const rt_ray r = rays[i];
+        const f3 o = ld3(r.origin), d = ld3(r.direction);
+        Cand best; int leaf;
+        trace_closest<COUNT>(sc, o, d, r.time, s_stack + threadIdx.x, ovf + gtid, ovf_stride, best, leaf, cn, cb, ct, cs);
+        HitOut h;
+        finalize_hit(sc, o, d, r.time, best, h);
+        rt_hit out;
+        out.t = h.t; out.shape = h.shape;
+        out.ip[0] = h.ip.x; out.ip[1] = h.ip.y; out.ip[2] = h.ip.z;
+        out.n[0] = h.n.x; out.n[1] = h.n.y; out.n[2] = h.n.z;
+        out.uv[0] = h.u; out.uv[1] = h.v;
+        hits[i] = out;
+    }
+    flush_counters<COUNT>(counters, cn, cb, ct, cs);
+}
+
+static int trace_blocks(int n) {
+    int want = (n + TRACE_BLOCK - 1) / TRACE_BLOCK;
+    int cap = NUM_CUS * TRACE_BLOCKS_PER_CU;
+    return want < cap ? (want < 1 ? 1 : want) : cap;
+}
+void rt_launch_trace(hipStream_t s, const DevScene &sc, LevelBuf lv, int n, int *ovf, int ovf_depth, DevCounters *counters) {
+    (void)ovf_depth;
+    if (n <= 0) return;
+    if (counters) hipLaunchKernelGGL(k_trace<true>, dim3(trace_blocks(n)), dim3(TRACE_BLOCK), 0, s, sc, lv, n, ovf, rt_trace_grid_threads(), counters);
+    else hipLaunchKernelGGL(k_trace<false>, dim3(trace_blocks(n)), dim3(TRACE_BLOCK), 0, s, sc, lv, n, ovf, rt_trace_grid_threads(), counters);
+}
+void rt_launch_trace_shadow(hipStream_t s, const DevScene &sc, ShadowBuf sb, int n, int *ovf, int ovf_depth, DevCounters *counters) {
+    (void)ovf_depth;
+    if (n <= 0) return;
+    if (counters) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(trace_blocks(n)), dim3(TRACE_BLOCK), 0, s, sc, sb, n, ovf, rt_trace_grid_threads(), counters);
+    else hipLaunchKernelGGL(k_trace_shadow<false>, dim3(trace_blocks(n)), dim3(TRACE_BLOCK), 0, s, sc, sb, n, ovf, rt_trace_grid_threads(), counters);
+}
+void rt_launch_trace_batch(hipStream_t s, const DevScene &sc, const rt_ray *rays, rt_hit *hits, int n, int *ovf, int ovf_depth, DevCounters *counters) {
+    (void)ovf_depth;
+    if (n <= 0) return;
+    if (counters) hipLaunchKernelGGL(k_trace_batch<true>, dim3(trace_blocks(n)), dim3(TRACE_BLOCK), 0, s, sc, rays, hits, n, ovf, rt_trace_grid_threads(), counters);
+    else hipLaunchKernelGGL(k_trace_batch<false>, dim3(trace_blocks(n)), dim3(TRACE_BLOCK), 0, s, sc, rays, hits, n, ovf, rt_trace_grid_threads(), counters);
+}
+
+// ====================================================================================================
+// Ray generation
+// ====================================================================================================
+__device__ __forceinline__ f3 camera_direction(const DevCamera &c, int row, int col, float ho, float vo) {   // Camera.cpp:103-125
+    float hm = c.left + (col + ho) * c.pixel_w;
+    float vm = c.top - (row + vo) * c.pixel_h;
+    return normalize3(ld3(c.gaze) * c.distance + ld3(c.right) * hm + ld3(c.up) * vm);
+}
+
+__global__ __launch_bounds__(256) void k_raygen(DevCamera cam, const int *pixel_list, int first_pixel, int n, LevelBuf lv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int pixel = pixel_list[first_pixel + i / cam.spp];
+    const int s = i % cam.spp;
+    const int row = pixel / cam.nx, col = pixel % cam.nx;
+    f3 o = ld3(cam.pos), d;
+    float time = 0.0f;                                                 // Q21
+    if (cam.spp > 1) {
+        double u[4];
+        rng_slot(cam.seed, (unsigned)pixel, (unsigned)s, 1u, SLOT_PIXEL, u);
+        float sx = (s % cam.jitter_n) * cam.jitter_w;                 // FindIthPartition, acmath.h:901-907 (Q19)
+        float sy = (s / cam.jitter_n) * cam.jitter_w;
+        sx += (float)uni(u[0], 0.0f, cam.jitter_w);                   // PixelSampler.cpp:31-35
+        sy += (float)uni(u[1], 0.0f, cam.jitter_w);
+        d = camera_direction(cam, row, col, sx, sy);
+        if (cam.aperture > 0) {                                        // ApplyLensTilt, Camera.cpp:132-147 (Q25)
+            float ax = (float)uni(u[2], -cam.aperture / 2.0, cam.aperture / 2.0);
+            float ay = (float)uni(u[3], -cam.aperture / 2.0, cam.aperture / 2.0);
+            f3 moved = ld3(cam.pos) + ld3(cam.right) * ax + ld3(cam.up) * ay;
+            float td = cam.focus / dot3(d, ld3(cam.gaze));
+            f3 p = o + d * td;
+            d = normalize3(p - moved);
+            o = moved;
+        }
+        double ut[4];
+        rng_slot(cam.seed, (unsigned)pixel, (unsigned)s, 1u, SLOT_TIME, ut);
+        time = (float)uni(ut[0], 0.0, 1.0);                           // MultiSampledRayGenerator.cpp:30
+    } else {
+        d = camera_direction(cam, row, col, 0.5f, 0.5f);              // Camera.cpp:76-79
+    }
+    lv.ray_o[i] = make_float4(o.x, o.y, o.z, time);
+    lv.ray_d[i] = make_float4(d.x, d.y, d.z, 1.0f);                   // Material::DefaultMaterial: n = 1
+    lv.ray_m[i] = make_int4(pixel, s, 1, -1);
+}
+void rt_launch_raygen(hipStream_t s, const DevCamera &cam, const int *pixel_list, int first_pixel, int n_samples, LevelBuf lv) {
+    if (n_samples <= 0) return;
+    hipLaunchKernelGGL(k_raygen, dim3((n_samples + 255) / 256), dim3(256), 0, s, cam, pixel_list, first_pixel, n_samples, lv);
+}
+
+// ====================================================================================================
+// Textures (Q22, Q23)
+// ====================================================================================================
+__device__ __forceinline__ float lerpf(float a, float b, float t) { return (1 - t) * a + t * b; }             // acmath.h:696
+__device__ __forceinline__ float fade(float t) { return 6 * t * t * t * t * t - 15 * t * t * t * t + 10 * t * t * t; } // acmath.h:703
+
+__constant__ float c_grad[16][3] = {{1, 1, 0}, {-1, 1, 0}, {1, -1, 0}, {-1, -1, 0}, {1, 0, 1}, {-1, 0, 1}, {1, 0, -1}, {-1, 0, -1},
+                                    {0, 1, 1}, {0, -1, 1}, {0, 1, -1}, {0, -1, -1}, {1, 1, 0}, {-1, 1, 0}, {0, -1, 1}, {0, -1, -1}};
+
+__device__ __forceinline__ int perm_at(const rt_texture &tx, int i) { int r = i % 16; if (r < 0) r += 16; return tx.perm[r]; }
+__device__ __forceinline__ float grad_dot(const rt_texture &tx, int i, int j, int k, float x, float y, float z) {
+    const int g = perm_at(tx, i + perm_at(tx, j + perm_at(tx, k)));
+    return c_grad[g][0] * x + c_grad[g][1] * y + c_grad[g][2] * z;
+}
+__device__ float perlin_value(const rt_texture &tx, float u, float v, float w) {                               // PerlinTextureImpl.cpp:74-140
+    const float px = u * tx.noise_scale, py = v * tx.noise_scale, pz = w * tx.noise_scale;
+    const int fx = (int)floorf(px), fy = (int)floorf(py), fz = (int)floorf(pz);
+    const int x0 = fx % 16, y0 = fy % 16, z0 = fz % 16;
+    const int x1 = (x0 + 1) % 16, y1 = (y0 + 1) % 16, z1 = (z0 + 1) % 16;
+    const float dxf = px - fx, dyf = py - fy, dzf = pz - fz;
+    const float dxc = dxf - 1, dyc = dyf - 1, dzc = dzf - 1;
+    const float w0 = fade(dxf), w1 = fade(dyf), w2 = fade(dzf);
+    const float l0 = lerpf(grad_dot(tx, x0, y0, z0, dxf, dyf, dzf), grad_dot(tx, x1, y0, z0, dxc, dyf, dzf), w0);
+    const float l1 = lerpf(grad_dot(tx, x0, y1, z0, dxf, dyc, dzf), grad_dot(tx, x1, y1, z0, dxc, dyc, dzf), w0);
+    const float l2 = lerpf(grad_dot(tx, x0, y0, z1, dxf, dyf, dzc), grad_dot(tx, x1, y0, z1, dxc, dyf, dzc), w0);
+    const float l3 = lerpf(grad_dot(tx, x0, y1, z1, dxf, dyc, dzc), grad_dot(tx, x1, y1, z1, dxc, dyc, dzc), w0);
+    float r = lerpf(lerpf(l0, l1, w1), lerpf(l2, l3, w1), w2);
+    if (tx.noise_conversion == RT_NOISE_ABSVAL) r = fabsf(r); else r = (r + 1) / 2.0f;
+    return r;
+}
+__device__ __forceinline__ int wrap_once(int c, int hi) { return c > hi ? 0 : (c < 0 ? hi : c); }              // TextureReader.cpp:89-95
+__device__ f3 fetch_texel(const DevScene &sc, const rt_texture &tx, int row, int col) {
+    row = wrap_once(row, tx.height - 1); col = wrap_once(col, tx.width - 1);
+    const long long idx = 3ll * ((long long)row * tx.width + col);
+    if (tx.texel_is_float) { const float *f = reinterpret_cast<const float *>(sc.texels + tx.texel_offset); return mk3(f[idx], f[idx + 1], f[idx + 2]); }
+    const uint8_t *b = sc.texels + tx.texel_offset;
+    return mk3((float)b[idx], (float)b[idx + 1], (float)b[idx + 2]);
+}
+__device__ f3 image_rgb(const DevScene &sc, const rt_texture &tx, float u, float v) {                          // TextureValueRetrieveMethod.cpp:20-55
+    if (u > 1.0f) u = u - (int)u;
+    if (v > 1.0f) v = v - (int)v;
+    const float rc = u * (tx.width - 1), rr = v * (tx.height - 1);
+    if (!tx.bilinear) return fetch_texel(sc, tx, (int)round((double)rr), (int)round((double)rc));
+    const int row = (int)floor((double)rr), col = (int)floor((double)rc);
+    const float ro = rr - row, co = rc - col;
+    return fetch_texel(sc, tx, row, col) * (1 - ro) * (1 - co) + fetch_texel(sc, tx, row + 1, col) * (ro) * (1 - co) +
+           fetch_texel(sc, tx, row, col + 1) * (1 - ro) * (co) + fetch_texel(sc, tx, row + 1, col + 1) * (ro) * (co);
+}
+__device__ f3 texture_rgb(const DevScene &sc, const rt_texture &tx, float u, float v, float w) {               // Texture.cpp:23-29
+    if (tx.kind == RT_TEX_PERLIN) { float r = perlin_value(tx, u, v, w); return mk3(r, r, r); }
+    return image_rgb(sc, tx, u, v);
+}
+
+struct Surf {          // the SurfaceIntersection fields shading needs
+    f3 ip, n; float u, v, theta, phi;
+    int shape, object, prim;
+};
+
+__device__ f3 diffuse_coefficient(const DevScene &sc, const rt_material &m, int tex_color, const Surf &s) {    // Intersection.cpp:31-42, ColorChangerTexture.cpp
+    const f3 kd = ld3(m.kd);
+    if (tex_color < 0) return kd;
+    const rt_texture &tx = sc.textures[tex_color];
+    f3 base;
+    if (tx.decal == RT_DECAL_REPLACE_KD || tx.decal == RT_DECAL_BLEND_KD) {
+        if (tx.kind == RT_TEX_PERLIN) base = texture_rgb(sc, tx, s.ip.x, s.ip.y, s.ip.z);
+        else base = image_rgb(sc, tx, s.u, s.v) / (float)tx.normalizer;
+        if (tx.decal == RT_DECAL_REPLACE_KD) return base;
+        f3 r = (kd + base) / 2;
+        return mk3(clampf(r.x, 0.0f, 1.0f), clampf(r.y, 0.0f, 1.0f), clampf(r.z, 0.0f, 1.0f));
+    }
+    return texture_rgb(sc, tx, s.u, s.v, 0.0f);
+}
+
+__device__ f3 perlin_bump(const rt_texture &tx, const Surf &s) {                                               // PerlinTextureImpl.cpp:45-67
+    const float e = 0.001f;
+    const float c0 = perlin_value(tx, s.ip.x, s.ip.y, s.ip.z);
+    const float cx = perlin_value(tx, s.ip.x + e, s.ip.y, s.ip.z);
+    const float cy = perlin_value(tx, s.ip.x, s.ip.y + e, s.ip.z);
+    const float cz = perlin_value(tx, s.ip.x, s.ip.y, s.ip.z + e);
+    const f3 diff = mk3((cx - c0) / e, (cy - c0) / e, (cz - c0) / e);
+    const f3 gp = dot3(diff, s.n) * s.n;
+    f3 gn = diff - gp;
+    gn = s.n - gn * tx.bump_factor;
+    return normalize3(gn);
+}
+__device__ f3 image_normal_value(const DevScene &sc, const rt_texture &tx, float u, float v) {                 // ImageTextureImpl.cpp:87-94
+    const f3 n = image_rgb(sc, tx, u, v) / 255.0f;
+    return normalize3(mk3((n.x - 0.5f) * 2.0f, (n.y - 0.5f) * 2.0f, (n.z - 0.5f) * 2.0f));
+}
+__device__ void image_color_values(const DevScene &sc, const rt_texture &tx, float uu, float vv, float off, float &c0, float &ch, float &cv) { // :157-176
+    const float u = uu - floorf(uu), v = vv - floorf(vv);
+    const float mul = tx.bump_factor / 255;
+    const f3 a = image_rgb(sc, tx, u, v) * mul, h = image_rgb(sc, tx, u + off, v) * mul, w = image_rgb(sc, tx, u, v + off) * mul;
+    c0 = (a.x + a.y + a.z) / 3; ch = (h.x + h.y + h.z) / 3; cv = (w.x + w.y + w.z) / 3;
+}
+// tangent / bitangent of a triangle from inverse(uv edge matrix) * position edge matrix (ImageTextureImpl.cpp:40-49, 131-141)
+__device__ void triangle_tangents(const DevScene &sc, const DevPrim &P, bool negate_uv, f3 ea, f3 eb, f3 &tangent, f3 &bitangent) {
+    const int *tv = sc.tri_vert + 3 * (size_t)P.shape;
+    const DevVertex &a = sc.verts[tv[0]], &b = sc.verts[tv[1]], &c = sc.verts[tv[2]];
+    float e1x = -(a.uv[0] - b.uv[0]), e1y = -(a.uv[1] - b.uv[1]), e2x = -(a.uv[0] - c.uv[0]), e2y = -(a.uv[1] - c.uv[1]);
+    float m00 = e1x, m01 = e2x, m10 = e1y, m11 = e2y;                  // m[col][row]
+    if (negate_uv) { m00 = -m00; m01 = -m01; m10 = -m10; m11 = -m11; }
+    const float ood = 1.0f / (+m00 * m11 - m10 * m01);                // glm::inverse(mat2)
+    const float i00 = +m11 * ood, i01 = -m01 * ood, i10 = -m10 * ood, i11 = +m00 * ood;
+    const f3 rx = mk3(i00 * ea.x + i10 * eb.x, i00 * ea.y + i10 * eb.y, i00 * ea.z + i10 * eb.z);
+    const f3 ry = mk3(i01 * ea.x + i11 * eb.x, i01 * ea.y + i11 * eb.y, i01 * ea.z + i11 * eb.z);
+    tangent = normalize3(rx); bitangent = normalize3(ry);
+}
+__device__ void sphere_tbn(const DevPrim &P, const Surf &s, f3 &tangent, f3 &bitangent, f3 &normal) {          // ImageTextureImpl.cpp:203-228
+    const double PI = 3.14159265;
+    const float radius = P.e1[0];
+    const float x = (float)(radius * sin(s.v * PI) * cos(PI - 2 * s.u * PI));
+    const float y = (float)(radius * cos(s.v * PI));
+    const float z = (float)(radius * sin(s.v * PI) * sin(PI - 2 * s.u * PI));
+    const f3 T = mk3((float)(2 * z * PI), .0f, (float)(-2 * x * PI));
+    const f3 B = mk3((float)(y * cosf(s.phi) * PI), (float)(-radius * sinf(s.theta) * PI), (float)(y * sinf(s.phi) * PI));
+    tangent = normalize3(T); bitangent = normalize3(B); normal = s.n;
+    tangent = tangent - normal * dot3(tangent, normal);
+    bitangent = bitangent - dot3(bitangent, normal) * normal - dot3(tangent, bitangent) * tangent;
+}
+// SurfaceIntersection::TweakSurfaceNormal (Intersection.cpp:25-29, NormalChangerTexture.cpp)
+__device__ __noinline__ f3 tweak_normal(const DevScene &sc, const Surf &s, int tex_normal) {
+    const rt_texture &tx = sc.textures[tex_normal];
+    const DevPrim &P = sc.prims[s.prim];
+    const bool tri = P.kind == DEV_PRIM_TRIANGLE;
+    if (tx.decal == RT_DECAL_REPLACE_NORMAL) {
+        if (tx.kind == RT_TEX_PERLIN) return mk3(0, 0, 0);             // PerlinTextureImpl.cpp:16-24
+        const f3 tn = image_normal_value(sc, tx, s.u, s.v);
+        if (tri) {                                                     // ImageTextureImpl.cpp:36-55
+            f3 t, b;
+            triangle_tangents(sc, P, true, ld3(P.e1), ld3(P.e2), t, b);
+            const f3 n = ld3(P.nrm);
+            return mk3(t.x * tn.x + b.x * tn.y + n.x * tn.z, t.y * tn.x + b.y * tn.y + n.y * tn.z, t.z * tn.x + b.z * tn.y + n.z * tn.z);
+        }
+        f3 t, b, n;
+        sphere_tbn(P, s, t, b, n);
+        return normalize3(mk3(t.x * tn.x + b.x * tn.y + n.x * tn.z, t.y * tn.x + b.y * tn.y + n.y * tn.z, t.z * tn.x + b.z * tn.y + n.z * tn.z));
+    }
+    if (tx.decal != RT_DECAL_BUMP_NORMAL) return s.n;
+    if (tx.kind == RT_TEX_PERLIN) return perlin_bump(tx, s);
+    if (tri) {                                                         // ImageTextureImpl.cpp:96-155
+        const DevObject &ob = sc.objects[P.object];
+        const f3 e1 = -ld3(P.e1), e2 = -ld3(P.e2);
+        const f3 ea = mat_mul_xyz(ob.M, e1.x, e1.y, e1.z, 0.0f), eb = mat_mul_xyz(ob.M, e2.x, e2.y, e2.z, 0.0f);
+        f3 t, b;
+        triangle_tangents(sc, P, false, ea, eb, t, b);
+        const f3 n = cross3(t, b);
+        t = t - n * dot3(t, n);
+        b = b - dot3(b, n) * n - dot3(t, b) * t;
+        float c0, ch, cv;
+        image_color_values(sc, tx, s.u, s.v, 0.001f, c0, ch, cv);
+        return cross3(t + (ch - c0) * n, b + (cv - c0) * n);
+    }
+    f3 t, b, n;                                                        // ImageTextureImpl.cpp:190-243
+    sphere_tbn(P, s, t, b, n);
+    float c0, ch, cv;
+    image_color_values(sc, tx, s.u, s.v, 0.002f, c0, ch, cv);
+    f3 bumped = n - t * (ch - c0) - b * (cv - c0);
+    bumped = bumped * (1.0f / sqrtf(dot3(bumped, bumped)));            // glm::normalize
+    if (dot3(bumped, n) < 0) bumped = bumped * -1.0f;
+    return bumped;
+}
+
+// ====================================================================================================
+// Lights and BRDFs (Q16, Q17)
+// ====================================================================================================
+__device__ void light_vars(const rt_light &L, int li, f3 ip, unsigned seed, const int4 meta, f3 &to_light, float &dist) {   // Light.cpp:89-129
+    if (L.type == RT_LIGHT_DIRECTIONAL) {
+        dist = 1e9;
+        to_light = normalize3(-ld3(L.direction));
+        return;
+    }
+    f3 pos = ld3(L.position);
+    if (L.type == RT_LIGHT_AREA) {
+        double u[4];
+        rng_slot(seed, (unsigned)meta.x, (unsigned)meta.y, (unsigned)meta.z, SLOT_LIGHT0 + li, u);
+        double p1 = uni(u[0], 0.0f, 1.0f), p2 = uni(u[1], 0.0f, 1.0f);
+        p1 -= 0.5; p2 -= 0.5;
+        const f3 to_right = ((float)p1 * L.size) * mk3(1.0f, 0.0f, 0.0f);
+        const f3 to_up = ((float)p2 * L.size) * mk3(0.0f, 0.0f, 1.0f);
+        pos = pos + to_up + to_right;
+    }
+    to_light = pos - ip;
+    dist = norm3(to_light);
+    to_light = normalize3(to_light);
+}
+__device__ f3 light_intensity(const rt_light &L, f3 to_light, float dist) {                                     // Light.cpp:58-87
+    const f3 I = ld3(L.intensity);
+    if (L.type == RT_LIGHT_DIRECTIONAL) return I;
+    if (L.type == RT_LIGHT_SPOT) {
+        const float deg2rad = 3.1415926f / 180.0f, rad2deg = 180.0f / 3.1415926f;
+        const float cos_cov = cosf(L.coverage_deg * deg2rad / 2);
+        const float theta = acosf(-dot3(to_light, ld3(L.direction)));
+        const float falloff = (cosf(theta) - cos_cov) / (cosf(L.falloff_deg * deg2rad / 2) - cos_cov);
+        if (theta * rad2deg > L.coverage_deg / 2) return mk3(0, 0, 0);
+        f3 faded = I / (dist * dist);
+        if (theta * rad2deg > L.falloff_deg / 2) faded = faded * falloff;
+        return faded;
+    }
+    if (L.type == RT_LIGHT_AREA) return I * fabsf(dot3(-to_light, ld3(L.direction))) * L.size * L.size / (dist * dist);
+    return I / (dist * dist);
+}
+__device__ float torrance_fr(const rt_material &m, float cosb, float ri) {                                       // brdf.cpp:18-46
+    cosb = clampf(cosb, -1, 1);
+    if (!(cosb > 0)) cosb = -cosb;
+    const float n1 = ri;
+    const float c2 = cosb * cosb, nk = n1 * n1 + m.absorption_index * m.absorption_index, n2c = 2 * n1 * cosb;
+    const float Rs = (nk - n2c + c2) / (nk + n2c + c2), Rp = (nk * c2 - n2c + 1) / (nk * c2 + n2c + 1);
+    return 0.5f * (Rs + Rp);
+}
+__device__ f3 brdf_eval(const rt_material &m, f3 wi, f3 wo, f3 n, f3 kd, f3 ks, float ri) {                      // brdf.cpp:58-170
+    const float pi = 3.14159265f;
+    const float e = m.brdf_exponent;
+    const f3 zero = mk3(0, 0, 0);
+    if (m.brdf_kind == RT_BRDF_BLINNPHONG_ORIGINAL) {
+        const float cost = dot3(wi, n);
+        if (cost <= 0) return zero;
+        return kd * cost + ks * powf(fmaxf(0.0f, dot3(n, normalize3(wi + wo))), e);
+    }
+    if (m.brdf_kind == RT_BRDF_BLINNPHONG_MODIFIED) {
+        const float cost = dot3(wi, n);
+        if (cost < 0) return zero;
+        if (!((double)acosf(cost) < pi / 2.0)) return zero;
+        if (m.brdf_flag) return (kd * (1.0f / pi) + (ks * (e + 8) * powf(fmaxf(0.0f, dot3(n, normalize3(wi + wo))), e) / (8 * pi))) * cost;
+        return (kd + ks * powf(fmaxf(0.0f, dot3(n, normalize3(wi + wo))), e)) * cost;
+    }
+    if (m.brdf_kind == RT_BRDF_PHONG_ORIGINAL) {
+        const float cost = dot3(wi, n);
+        if (cost < 0.0f) return zero;
+        if ((double)acosf(cost) < pi / 2.0) return kd * cost + ks * powf(dot3(wo, normalize3(wi - 2.0f * n * cost)), e);
+        return zero;
+    }
+    if (m.brdf_kind == RT_BRDF_PHONG_MODIFIED) {
+        const float cost = dot3(wi, n);
+        if (cost < 0.0f) return zero;
+        if (!((double)acosf(cost) < pi / 2.0)) return zero;
+        if (m.brdf_flag) return (kd * (1.0f / pi) + ks * (e + 2) * powf(dot3(wo, wi - 2.0f * n * cost), e) / (2.0f * pi)) * cost;
+        return (kd + ks * powf(dot3(wo, wi - 2.0f * n * cost), e)) * cost;
+    }
+    const float cost = dot3(n, wi);                                    // Torrance-Sparrow
+    if (cost < 0) return zero;
+    if ((double)acosf(cost) < pi / 2.0) {
+        const f3 wh = normalize3(wi + wo);
+        const float cosa = fmaxf(0.0f, dot3(n, wh)), cosb = fmaxf(0.0f, dot3(wo, wh)), cosc = dot3(wo, n);
+        const float dterm = powf(cosa, e) * (e + 2) / (2.0f * pi);
+        const float g = fminf(1.0f, dot3(n, wh) * 2.0f / dot3(wo, wh) * fminf(dot3(n, wo), dot3(n, wi)));
+        if (m.brdf_flag) return (1.0f - torrance_fr(m, cosb, ri)) * kd * (1.0f / pi) * cost + ks * g * torrance_fr(m, cosb, ri) * dterm / (4.0f * cosc);
+        return kd * (1.0f / pi) * cost + ks * g * dterm / (4.0f * cosc);
+    }
+    return zero;
+}
+
+// ====================================================================================================
+// Shading
+// ====================================================================================================
+__device__ __forceinline__ Surf load_surf(const LevelBuf &lv, int i, float &t) {
+    const float4 h0 = lv.hit0[i], h1 = lv.hit1[i], h2 = lv.hit2[i], h3 = lv.hit3[i];
+    Surf s;
+    t = h0.x; s.shape = __float_as_int(h0.y); s.object = __float_as_int(h0.z); s.prim = __float_as_int(h0.w);
+    s.ip = mk3(h1.x, h1.y, h1.z); s.n = mk3(h1.w, h2.x, h2.y); s.u = h2.z; s.v = h2.w; s.theta = h3.x; s.phi = h3.y;
+    return s;
+}
+__device__ __forceinline__ bool replaces_all(const DevScene &sc, const DevObject &ob) {
+    return ob.tex_color >= 0 && sc.textures[ob.tex_color].decal == RT_DECAL_REPLACE_ALL;
+}
+
+// Per hit: texture-tweaked normal (written back into the hit record) and one shadow ray per light.
+__global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, LevelBuf lv, int n, ShadowBuf sb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int nl = sc.p.n_lights;
+    float t;
+    Surf s = load_surf(lv, i, t);
+    const int4 meta = lv.ray_m[i];
+    bool lit = s.shape >= 0 || s.object >= 0;
+    lit = s.object >= 0;
+    if (lit) {
+        const DevObject &ob = sc.objects[s.object];
+        if (replaces_all(sc, ob)) lit = false;                         // LightContributionCalculator.cpp:54-55
+        else {
+            if (ob.tex_normal >= 0) {
+                s.n = tweak_normal(sc, s, ob.tex_normal);
+                lv.hit1[i].w = s.n.x;
+                float4 h2 = lv.hit2[i];
+                h2.x = s.n.y; h2.y = s.n.z;
+                lv.hit2[i] = h2;
+            }
+            if (meta.w >= 0 && meta.w == s.object) lit = false;        // IsInternalReflection (Q26)
+        }
+    }
+    const float time = lv.ray_o[i].w;
+    for (int l = 0; l < nl; ++l) {
+        const int k = i * nl + l;
+        if (!lit) { sb.ipref[k] = make_float4(0, 0, 0, 0); continue; }
+        f3 to_light; float dist;
+        light_vars(sc.lights[l], l, s.ip, cam.seed, meta, to_light, dist);
+        const f3 so = s.ip + s.n * sc.p.shadow_eps;                    // LightContributionCalculator.cpp:133
+        sb.o[k] = make_float4(so.x, so.y, so.z, time);
+        sb.d[k] = make_float4(to_light.x, to_light.y, to_light.z, dist);
+        sb.ipref[k] = make_float4(s.ip.x, s.ip.y, s.ip.z, 1.0f);
+    }
+}
+void rt_launch_shade_pre(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, ShadowBuf sb) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_shade_pre, dim3((n + 255) / 256), dim3(256), 0, s, sc, cam, lv, n, sb);
+}
+
+// wave64 compaction: every lane asks for `want` (0..2) slots; one atomic per wave reserves the total; returns the
+// first slot of this lane.  __ballot is 64 bits wide on gfx950.
+__device__ __forceinline__ int wave_alloc(int want, int *counter) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long m1 = __ballot(want >= 1), m2 = __ballot(want >= 2);
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int prefix = __popcll(m1 & below) + __popcll(m2 & below);
+    const int total = __popcll(m1) + __popcll(m2);
+    int base = 0;
+    if (lane == 0 && total > 0) base = atomicAdd(counter, total);
+    base = __shfl(base, 0);
+    return base + prefix;
+}
+
+__global__ __launch_bounds__(256) void k_shade_post(DevScene sc, DevCamera cam, LevelBuf lv, int n, ShadowBuf sb, LevelBuf next, int depth,
+                                                    int *next_count, unsigned long long *kind_counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < n;
+    int want = 0;
+    // values carried from the "decide" half to the "emit" half
+    f3 L = mk3(0, 0, 0), mrc = mk3(0, 0, 0), absorb = mk3(1, 1, 1);
+    float refl_coef = 0, refr_coef = 0;
+    int flags = 0;
+    bool has_refr = false, has_refl = false;
+    f3 refl_o, refl_d, refr_o, refr_d;
+    float refl_n = 1, refr_n = 1, time = 0;
+    int refl_c = -1, refr_c = -1;
+    int4 meta = make_int4(0, 0, 0, -1);
+    int n_shadow = 0;
+    if (active) {
+        float t;
+        const Surf s = load_surf(lv, i, t);
+        meta = lv.ray_m[i];
+        const float4 ro = lv.ray_o[i], rd = lv.ray_d[i];
+        const f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
+        time = ro.w;
+        if (s.object < 0) {                                            // miss: outColor = background (Q10)
+            if (sc.p.bg_texture >= 0) L = texture_rgb(sc, sc.textures[sc.p.bg_texture], 0.0f, 0.0f, 0.0f);
+            else L = ld3(sc.p.background);
+        } else {
+            flags = NODE_HIT;
+            const DevObject &ob = sc.objects[s.object];
+            const rt_material &m = sc.materials[ob.material];
+            if (replaces_all(sc, ob)) {
+                L = texture_rgb(sc, sc.textures[ob.tex_color], s.u, s.v, 0.0f);
+            } else {
+                const bool internal = meta.w >= 0 && meta.w == s.object;
+                const f3 to_viewer = normalize3(o - s.ip);             // LightContributionCalculator.cpp:75
+                if (!internal) {                                       // ProcessLights :98-124
+                    f3 all = mk3(0, 0, 0);
+                    all = all + ld3(sc.p.ambient) * ld3(m.ka);
+                    const int nl = sc.p.n_lights;
+                    for (int l = 0; l < nl; ++l) {
+                        const int k = i * nl + l;
+                        f3 c = mk3(0, 0, 0);
+                        ++n_shadow;
+                        if (!sb.occluded[k]) {
+                            const float4 sd = sb.d[k];
+                            const f3 to_light = mk3(sd.x, sd.y, sd.z);
+                            const f3 kd = diffuse_coefficient(sc, m, ob.tex_color, s);
+                            c = brdf_eval(m, to_light, to_viewer, s.n, kd, ld3(m.ks), m.refraction_index) * light_intensity(sc.lights[l], to_light, sd.w) * 1.0f;
+                        }
+                        all = all + c;
+                    }
+                    L = L + all;
+                }
+                if (depth < sc.p.max_depth && m.type != RT_MAT_DEFAULT) {
+                    // RecursiveComputation (RecursiveComputation.cpp:25-30)
+                    f3 N = normalize3(s.n);
+                    const float se = sc.p.shadow_eps;
+                    float fraction = 0;
+                    if (m.type == RT_MAT_DIELECTRIC || m.type == RT_MAT_CONDUCTOR) {
+                        // ComputeFresnel (:203-228)
+                        float n_out = rd.w, n_in = m.refraction_index;
+                        if (internal) n_in = 1;
+                        float corr = clampf(dot3(d, N), -1, 1);
+                        if (corr > 0) {
+                            if (m.type == RT_MAT_CONDUCTOR) { float sw = n_out; n_out = n_in; n_in = sw; }
+                            N = -N;
+                        } else corr = -corr;
+                        const float sin1 = sqrtf(1 - corr * corr);
+                        const float sin2 = (n_out * sin1) / n_in;
+                        const float cos2 = sqrtf(1 - sin2 * sin2);
+                        if (m.type == RT_MAT_DIELECTRIC) {             // Material.cpp:13-24
+                            const float n2c1 = n_in * corr, n1c2 = n_out * cos2;
+                            const float rpll = (n2c1 - n1c2) / (n2c1 + n1c2);
+                            const float n1c1 = n_out * corr, n2c2 = n_in * cos2;
+                            const float rperp = (n1c1 - n2c2) / (n1c1 + n2c2);
+                            fraction = 0.5f * (rpll * rpll + rperp * rperp);
+                        } else {                                       // Material.cpp:26-38 (Q13)
+                            const float n1 = m.refraction_index;
+                            const float c2 = corr * corr, nk = n1 * n1 + m.absorption_index * m.absorption_index, n2c = 2 * n1 * corr;
+                            const float Rs = (nk - n2c + c2) / (nk + n2c + c2), Rp = (nk * c2 - n2c + 1) / (nk * c2 + n2c + 1);
+                            fraction = 0.5f * (Rs + Rp);
+                        }
+                        // ComputeRefractionParameters (:181-201), PerformRefraction (:154-179) (Q14)
+                        const float param = n_out / n_in;
+                        const float cost = 1 - corr * corr;
+                        const float det = 1 - param * param * cost;
+                        if (det >= 0) {
+                            has_refr = true;
+                            refr_d = normalize3((d + N * corr) * (param)-N * sqrtf(det));
+                            refr_o = s.ip + -N * se;
+                            if (!internal) { refr_n = m.refraction_index; refr_c = s.object; }
+                            else { refr_n = 1.0f; refr_c = -1; }
+                        } else if (internal) fraction = 1;
+                        refr_coef = 1 - fraction;
+                    }
+                    // reflection ray (:62-122)
+                    const f3 to_viewer2 = normalize3(o - s.ip);
+                    f3 vrd = normalize3(N * 2.0f * dot3(to_viewer2, N) - to_viewer2);
+                    if (m.type != RT_MAT_DIELECTRIC && m.roughness > 0) {   // glossy tilt (Q15); the dielectric path does not call it
+                        const int mi = fabsf(vrd.x) < fabsf(vrd.y) ? (fabsf(vrd.x) < fabsf(vrd.z) ? 0 : 2) : (fabsf(vrd.y) < fabsf(vrd.z) ? 1 : 2);
+                        f3 rp = vrd;
+                        if (mi == 0) rp.x = 1.0f; else if (mi == 1) rp.y = 1.0f; else rp.z = 1.0f;
+                        rp = normalize3(rp);
+                        const f3 u = normalize3(cross3(vrd, rp));
+                        const f3 v = normalize3(cross3(vrd, u));
+                        double uu[4];
+                        rng_slot(cam.seed, (unsigned)meta.x, (unsigned)meta.y, (unsigned)meta.z, SLOT_GLOSSY, uu);
+                        const f3 r1 = (float)uni(uu[0], -0.5, 0.5) * u;
+                        const f3 r2 = (float)uni(uu[1], -0.5, 0.5) * v;
+                        vrd = normalize3(vrd + m.roughness * (r1 + r2));
+                    }
+                    has_refl = true;
+                    refl_o = s.ip + N * se;
+                    refl_d = vrd;
+                    refl_n = rd.w; refl_c = meta.w;                    // inherits currMat / currShape (Q26)
+                    if (m.type == RT_MAT_MIRROR) { mrc = ld3(m.km); refl_coef = m.degamma ? 2.2f : 1.0f; flags |= NODE_REFL_MRC; }
+                    else if (m.type == RT_MAT_CONDUCTOR) { mrc = ld3(m.km); refl_coef = fraction; flags |= NODE_REFL_MRC; }
+                    else {
+                        refl_coef = fraction; flags |= NODE_REFL_ALWAYS;
+                        if (internal) {                                // GetDielectricPowerAbsorptionParameter (:143-152, Q12)
+                            const f3 ac = ld3(m.ac);
+                            const float distance = (s.ip.x - o.x) / d.x;
+                            const float ecoeff = expf(-(0.01f * distance));
+                            absorb = ecoeff * mk3(expf(-ac.x * distance), expf(-ac.y * distance), expf(-ac.z * distance));
+                            flags |= NODE_ABSORB;
+                        }
+                    }
+                }
+            }
+        }
+        want = (has_refr ? 1 : 0) + (has_refl ? 1 : 0);
+    }
+    // ---- compaction into the next level's queue ----
+    int slot = wave_alloc(want, next_count);
+    int ci_refr = -1, ci_refl = -1;
+    if (active) {
+        if (has_refr) {
+            ci_refr = slot++;
+            next.ray_o[ci_refr] = make_float4(refr_o.x, refr_o.y, refr_o.z, time);
+            next.ray_d[ci_refr] = make_float4(refr_d.x, refr_d.y, refr_d.z, refr_n);
+            next.ray_m[ci_refr] = make_int4(meta.x, meta.y, meta.z * 2, refr_c);
+        }
+        if (has_refl) {
+            ci_refl = slot++;
+            next.ray_o[ci_refl] = make_float4(refl_o.x, refl_o.y, refl_o.z, time);
+            next.ray_d[ci_refl] = make_float4(refl_d.x, refl_d.y, refl_d.z, refl_n);
+            next.ray_m[ci_refl] = make_int4(meta.x, meta.y, meta.z * 2 + 1, refl_c);
+        }
+        lv.node_a[i] = make_float4(L.x, L.y, L.z, __int_as_float(flags));
+        lv.node_b[i] = make_float4(mrc.x, mrc.y, mrc.z, refl_coef);
+        lv.node_c[i] = make_float4(absorb.x, absorb.y, absorb.z, refr_coef);
+        lv.child[i] = make_int2(ci_refr, ci_refl);
+    }
+    if (kind_counts) {      // rays per kind (one "ray" = one closest-hit query): shadow rays of this level, children of the next
+        unsigned a = active ? (unsigned)n_shadow : 0u, b = has_refl ? 1u : 0u, c = has_refr ? 1u : 0u;
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); c += __shfl_down(c, off); }
+        if ((threadIdx.x & 63) == 0) {
+            if (a) atomicAdd(&kind_counts[RT_RAY_SHADOW], (unsigned long long)a);
+            if (b) atomicAdd(&kind_counts[RT_RAY_REFLECT], (unsigned long long)b);
+            if (c) atomicAdd(&kind_counts[RT_RAY_REFRACT], (unsigned long long)c);
+        }
+    }
+}
+void rt_launch_shade_post(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, ShadowBuf sb, LevelBuf next, int depth,
+                          int *next_count, unsigned long long *kind_counts) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_shade_post, dim3((n + 255) / 256), dim3(256), 0, s, sc, cam, lv, n, sb, next, depth, next_count, kind_counts);
+}
+
+// Backward sweep: colour(ray) = local + children, in the association order of RecursiveComputation.cpp:62-69,130-141,172-173.
+__global__ __launch_bounds__(256) void k_backward(LevelBuf lv, int n, LevelBuf next, int has_next) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = lv.node_a[i];
+    const int flags = __float_as_int(a.w);
+    f3 C = mk3(a.x, a.y, a.z);
+    const int2 ch = lv.child[i];
+    if (has_next && (ch.x >= 0 || ch.y >= 0)) {
+        const float4 b = lv.node_b[i], c = lv.node_c[i];
+        if (ch.x >= 0) {                                               // refraction: only if the child hit something (Q11)
+            const float4 cc = next.color[ch.x];
+            if (cc.w != 0.0f) C = C + mk3(cc.x, cc.y, cc.z) * c.w;
+        }
+        if (ch.y >= 0) {
+            const float4 cc = next.color[ch.y];
+            const f3 col = mk3(cc.x, cc.y, cc.z);
+            if (flags & NODE_REFL_ALWAYS) C = C + col * b.w;
+            else if (cc.w != 0.0f) C = C + col * mk3(b.x, b.y, b.z) * b.w;
+        }
+        if (flags & NODE_ABSORB) C = C * mk3(c.x, c.y, c.z);
+    }
+    lv.color[i] = make_float4(C.x, C.y, C.z, (flags & NODE_HIT) ? 1.0f : 0.0f);
+}
+void rt_launch_backward(hipStream_t s, LevelBuf lv, int n, LevelBuf next, int has_next) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_backward, dim3((n + 255) / 256), dim3(256), 0, s, lv, n, next, has_next);
+}
+
+// RenderMultiSampled's mean (DefaultRenderer.cpp:111-122) / RenderWithOneSample; also the primary hit id of sample 0.
+__global__ __launch_bounds__(256) void k_resolve(DevCamera cam, const int *pixel_list, int first_pixel, int n_pixels, LevelBuf lv0, int compact,
+                                                 float *hdr, int *prim_id, float *prim_t) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pixels) return;
+    const int spp = cam.spp;
+    f3 sum = mk3(0, 0, 0);
+    if (spp > 1) {
+        for (int s = 0; s < spp; ++s) { const float4 c = lv0.color[p * spp + s]; sum = sum + mk3(c.x, c.y, c.z); }
+        sum = mk3(sum.x / spp, sum.y / spp, sum.z / spp);
+    } else {
+        const float4 c = lv0.color[p];
+        sum = mk3(c.x, c.y, c.z);
+    }
+    const size_t dst = compact ? (size_t)(first_pixel + p) : (size_t)pixel_list[first_pixel + p];
+    hdr[3 * dst + 0] = sum.x; hdr[3 * dst + 1] = sum.y; hdr[3 * dst + 2] = sum.z;
+    if (prim_id || prim_t) {
+        const float4 h0 = lv0.hit0[p * spp];
+        if (prim_id) prim_id[dst] = __float_as_int(h0.y);
+        if (prim_t) prim_t[dst] = h0.x;
+    }
+}
+void rt_launch_resolve(hipStream_t s, const DevCamera &cam, const int *pixel_list, int first_pixel, int n_pixels, LevelBuf lv0, int compact,
+                       float *hdr, int *prim_id, float *prim_t) {
+    if (n_pixels <= 0) return;
+    hipLaunchKernelGGL(k_resolve, dim3((n_pixels + 255) / 256), dim3(256), 0, s, cam, pixel_list, first_pixel, n_pixels, lv0, compact, hdr, prim_id, prim_t);
+}

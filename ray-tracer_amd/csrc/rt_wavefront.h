@@ -1,0 +1,78 @@
+// rt_wavefront.h — per-bounce ray queues and the launch interface between rt_api.hip and rt_kernels.hip.
+//
+// The reference renders a pixel with one recursive C++ call (LightContributionCalculator::CalculateLight ->
+// RecursiveComputation -> CalculateLight ...).  Here recursion depth k becomes "level k": a structure-of-arrays
+// ray queue, traced and shaded by whole-queue kernels.  A forward sweep (levels 0..maxDepth) traces and shades
+// and appends children to the next level; a backward sweep (maxDepth..0) folds child colours into their
+// parents in exactly the reference's post-order association, so the result does not depend on queue order.
+#ifndef RT_WAVEFRONT_H_
+#define RT_WAVEFRONT_H_
+
+#include <hip/hip_runtime.h>
+
+#include "rt_device.h"
+
+// One level of the wavefront.  All arrays have `capacity` entries; 16-byte elements so that lane i of a
+// wave reads/writes base + 16*i (fully coalesced 1 KiB per wave instruction).
+struct LevelBuf {
+    // ray queue
+    float4 *ray_o;      // origin.xyz, time
+    float4 *ray_d;      // direction.xyz, refraction index of the medium the ray travels in (Ray::currMat)
+    int4 *ray_m;        // pixel index, sample index, path code, container object of the medium (Ray::currShape) or -1
+    // closest hit (written by trace, normal possibly re-written by shade_pre after texture tweaks)
+    float4 *hit0;       // t, shape (int bits), object (int bits), prim record (int bits)
+    float4 *hit1;       // ip.xyz, n.x
+    float4 *hit2;       // n.y, n.z, uv.x, uv.y
+    float4 *hit3;       // sphere theta, phi (SurfaceIntersection::lip), unused, unused
+    // shading node (written by shade_post, consumed by the backward sweep)
+    float4 *node_a;     // local light colour rgb, flags (int bits)
+    float4 *node_b;     // mirror reflectance rgb, reflection coefficient
+    float4 *node_c;     // absorption factor rgb, refraction coefficient
+    int2 *child;        // index of the refraction / reflection child in the next level, or -1
+    float4 *color;      // resolved colour rgb, hit flag
+    int capacity;
+    int count;
+};
+
+enum {
+    NODE_HIT = 1,            // ray hit something (what CalculateLight returns)
+    NODE_REFL_ALWAYS = 2,    // dielectric reflection: added even when the child misses (Q11)
+    NODE_REFL_MRC = 4,       // reflection colour is multiplied by MRC before the coefficient (mirror, conductor)
+    NODE_ABSORB = 8          // Beer absorption multiplies the accumulated colour (Q12)
+};
+
+struct ShadowBuf {
+    float4 *o;          // origin.xyz, time
+    float4 *d;          // direction.xyz, distance to the light
+    float4 *ipref;      // the shaded point ip.xyz, active flag (0 = no shadow ray for this slot)
+    int *occluded;      // result: 1 = an object lies between point and light (Q7)
+    int capacity;
+};
+
+struct DevCamera {
+    float pos[3], gaze[3], up[3], right[3];
+    float left, top, distance, pixel_w, pixel_h;
+    int nx, ny, spp;
+    int jitter_n;           // (int)sqrt(spp)  (Q19)
+    float jitter_w;         // 1.0f / jitter_n
+    float aperture, focus;
+    unsigned seed;
+};
+
+struct DevCounters {        // accumulated with atomics when counting is enabled
+    unsigned long long node_visits, box_tests, tri_tests, sphere_tests;
+};
+
+void rt_launch_raygen(hipStream_t s, const DevCamera &cam, const int *pixel_list, int first_pixel, int n_samples, LevelBuf lv);
+void rt_launch_trace(hipStream_t s, const DevScene &sc, LevelBuf lv, int n, int *overflow_stack, int overflow_depth, DevCounters *counters);
+void rt_launch_trace_shadow(hipStream_t s, const DevScene &sc, ShadowBuf sb, int n, int *overflow_stack, int overflow_depth, DevCounters *counters);
+void rt_launch_trace_batch(hipStream_t s, const DevScene &sc, const rt_ray *rays, rt_hit *hits, int n, int *overflow_stack, int overflow_depth, DevCounters *counters);
+void rt_launch_shade_pre(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, ShadowBuf sb);
+void rt_launch_shade_post(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, ShadowBuf sb, LevelBuf next, int depth, int *next_count, unsigned long long *ray_kind_counts);
+void rt_launch_backward(hipStream_t s, LevelBuf lv, int n, LevelBuf next, int has_next);
+void rt_launch_resolve(hipStream_t s, const DevCamera &cam, const int *pixel_list, int first_pixel, int n_pixels, LevelBuf lv0, int compact,
+                       float *hdr, int *prim_id, float *prim_t);
+int rt_trace_grid_threads();     // number of persistent threads the trace kernels are launched with
+int rt_trace_lds_stack_depth();  // stack entries kept in LDS per lane
+
+#endif

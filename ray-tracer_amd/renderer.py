@@ -1,0 +1,234 @@
+"""Host-side mirror of the reference's plugin interfaces for the accelerated path, on top of the C-ABI.
+
+    Mi355Renderer.RenderSceneIntoPPM(scene)   <->  RenderStrategy::RenderSceneIntoPPM(Scene*)      (src/RenderStrategy.h:16,
+                                                   DefaultRenderer, src/DefaultRenderer.cpp:35-162)
+    Mi355Accelerator.Intersect(rays)          <->  AccelerationStructure::Intersect(Ray&, ...)      (src/AccelerationStructure.h:21)
+
+Everything numerical happens inside librt_mi355.so (hand-written HIP for gfx950).  There is no CPU fallback: if the
+library or a GPU is missing, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librt_mi355.so")
+_lib = None
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("rt_mi355 error %d: %s" % (code, msg))
+        self.code = code
+
+
+def library():
+    """Loads librt_mi355.so (built in-tree by `make -C ray-tracer_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RtError(abi.RT_ERR_INVALID, "%s is missing: build it with `make -C ray-tracer_amd/csrc` (no fallback path exists)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    L.rt_abi_version.restype = C.c_uint32
+    L.rt_ctx_create.argtypes = [C.c_int, P(C.c_void_p)]
+    L.rt_ctx_destroy.argtypes = [C.c_void_p]
+    L.rt_ctx_destroy.restype = None
+    L.rt_last_error.argtypes = [C.c_void_p]
+    L.rt_last_error.restype = C.c_char_p
+    L.rt_scene_upload.argtypes = [C.c_void_p, P(abi.SceneDesc)]
+    L.rt_scene_bvh_info.argtypes = [C.c_void_p, P(abi.BvhInfo)]
+    L.rt_render.argtypes = [C.c_void_p, P(abi.CameraDesc), P(abi.RenderOpts), C.c_void_p, C.c_void_p, C.c_void_p, P(abi.Stats)]
+    L.rt_intersect_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, P(abi.Stats)]
+    L.rt_owned_pixel_count.argtypes = [C.c_int] * 5
+    L.rt_owned_pixel_count.restype = C.c_int64
+    L.rt_tile_pixel_order.argtypes = [C.c_int] * 5 + [C.c_void_p]
+    L.rt_perlin_tables.argtypes = [C.c_int, C.c_void_p]
+    L.rt_resolve_8bit.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    L.rt_host_bvh_build.argtypes = [P(abi.SceneDesc), P(C.c_void_p)]
+    L.rt_host_bvh_info.argtypes = [C.c_void_p, P(abi.BvhInfo)]
+    L.rt_host_bvh_leaves.argtypes = [C.c_void_p] * 6
+    L.rt_host_bvh_free.argtypes = [C.c_void_p]
+    L.rt_host_bvh_free.restype = None
+    L.rt_abi_sizeof.argtypes = [C.c_int]
+    if L.rt_abi_version() != abi.RT_ABI_VERSION:
+        raise RtError(abi.RT_ERR_ABI, "librt_mi355.so ABI %d != python mirror %d" % (L.rt_abi_version(), abi.RT_ABI_VERSION))
+    _lib = L
+    return L
+
+
+def perlin_tables(n):
+    out = np.zeros((max(n, 0), 16), np.int32)
+    rc = library().rt_perlin_tables(n, out.ctypes.data)
+    if rc != 0:
+        raise RtError(rc, "rt_perlin_tables")
+    return [out[i].copy() for i in range(n)]
+
+
+def tile_pixel_order(nx, ny, tile_size, rank, world):
+    n = library().rt_owned_pixel_count(nx, ny, tile_size, rank, world)
+    out = np.zeros(n, np.int32)
+    rc = library().rt_tile_pixel_order(nx, ny, tile_size, rank, world, out.ctypes.data)
+    if rc != 0:
+        raise RtError(rc, "rt_tile_pixel_order")
+    return out
+
+
+def resolve_8bit(hdr):
+    hdr = np.ascontiguousarray(hdr, np.float32)
+    out = np.zeros(hdr.shape, np.uint8)
+    library().rt_resolve_8bit(hdr.ctypes.data, hdr.size // 3, out.ctypes.data)
+    return out
+
+
+def host_bvh(soup):
+    """Host-only BVH view (no GPU): dict with info, reference leaf ranges / primitive order / boxes and device leaf runs."""
+    L = library()
+    d = soup.desc()
+    h = C.c_void_p()
+    rc = L.rt_host_bvh_build(C.byref(d), C.byref(h))
+    if rc != 0:
+        raise RtError(rc, L.rt_last_error(None).decode())
+    try:
+        info = abi.BvhInfo()
+        L.rt_host_bvh_info(h, C.byref(info))
+        se = np.zeros((info.n_leaves, 2), np.int64)
+        order = np.zeros(len(soup.prim_shape), np.int32)
+        boxes = np.zeros((info.n_leaves, 6), np.float32)
+        dsc = np.zeros((info.n_leaves, 2), np.int64)
+        dshape = np.zeros(info.n_leaf_prims, np.int32)
+        L.rt_host_bvh_leaves(h, se.ctypes.data, order.ctypes.data, boxes.ctypes.data, dsc.ctypes.data, dshape.ctypes.data)
+        return {"info": info, "leaf_start_end": se, "prim_order": order, "leaf_boxes": boxes, "dev_leaf_start_count": dsc, "dev_prim_shape": dshape}
+    finally:
+        L.rt_host_bvh_free(h)
+
+
+class Context:
+    """One rt_ctx: a HIP device, an uploaded scene and the wavefront buffers."""
+
+    def __init__(self, device=0):
+        self.L = library()
+        self.h = C.c_void_p()
+        rc = self.L.rt_ctx_create(device, C.byref(self.h))
+        if rc != 0:
+            raise RtError(rc, self.L.rt_last_error(None).decode())
+        self.device = device
+        self.soup = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RtError(rc, self.L.rt_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rt_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, soup):
+        d = soup.desc()
+        self._check(self.L.rt_scene_upload(self.h, C.byref(d)))
+        self.soup = soup
+        return self
+
+    def bvh_info(self):
+        info = abi.BvhInfo()
+        self._check(self.L.rt_scene_bvh_info(self.h, C.byref(info)))
+        return info
+
+    def make_opts(self, seed=0, tile_size=0, tile_rank=0, tile_world=1, output_on_device=False, compact_output=False,
+                  max_batch_samples=0, timing=0):
+        o = abi.RenderOpts()
+        o.abi_version = abi.RT_ABI_VERSION
+        o.seed, o.tile_size, o.tile_rank, o.tile_world = seed, tile_size, tile_rank, tile_world
+        o.output_on_device, o.compact_output = int(output_on_device), int(compact_output)
+        o.max_batch_samples, o.timing = max_batch_samples, int(timing)
+        return o
+
+    def render(self, cam=0, want_ids=True, **kw):
+        """Renders to host numpy arrays.  `cam` is a camera index of the uploaded soup or an abi.CameraDesc."""
+        cam_over = {k: kw.pop(k) for k in list(kw) if k in ("num_samples", "nx", "ny", "plane", "focus_distance", "aperture_size")}
+        cd = cam if isinstance(cam, abi.CameraDesc) else self.soup.camera_desc(cam, **cam_over)
+        opts = self.make_opts(**kw)
+        if opts.compact_output:
+            n = self.L.rt_owned_pixel_count(cd.nx, cd.ny, opts.tile_size, opts.tile_rank, opts.tile_world)
+            shape3, shape1 = (n, 3), (n,)
+        else:
+            shape3, shape1 = (cd.ny, cd.nx, 3), (cd.ny, cd.nx)
+        hdr = np.zeros(shape3, np.float32)
+        pid = np.zeros(shape1, np.int32) if want_ids else None
+        pt = np.zeros(shape1, np.float32) if want_ids else None
+        st = abi.Stats()
+        self._check(self.L.rt_render(self.h, C.byref(cd), C.byref(opts), hdr.ctypes.data, pid.ctypes.data if want_ids else None,
+                                     pt.ctypes.data if want_ids else None, C.byref(st)))
+        return hdr, pid, pt, st
+
+    def render_device(self, cd, opts, hdr_ptr, pid_ptr=None, pt_ptr=None, stats=None):
+        """Renders into caller-provided DEVICE buffers (opts.output_on_device must be 1)."""
+        st = stats if stats is not None else abi.Stats()
+        self._check(self.L.rt_render(self.h, C.byref(cd), C.byref(opts), hdr_ptr, pid_ptr, pt_ptr, C.byref(st)))
+        return st
+
+    def intersect(self, rays, stats=False):
+        rays = np.ascontiguousarray(rays, abi.ray_dtype)
+        hits = np.zeros(len(rays), abi.hit_dtype)
+        st = abi.Stats()
+        self._check(self.L.rt_intersect_batch(self.h, rays.ctypes.data, len(rays), hits.ctypes.data, 0, C.byref(st) if stats else None))
+        return (hits, st) if stats else hits
+
+
+class Mi355Accelerator:
+    """AccelerationStructure mirror (src/AccelerationStructure.h:12-26): built from a scene's primitives, answers closest-
+    hit queries — batched, because one ray per call cannot feed a GPU.  "No hit" is shape == -1 (reference: mat == nullptr)."""
+
+    def __init__(self, scene, device=0, context=None):
+        self.ctx = context or Context(device)
+        if context is None or context.soup is not scene:
+            self.ctx.upload(scene)
+
+    def Intersect(self, rays):
+        return self.ctx.intersect(rays)
+
+
+class Mi355Renderer:
+    """RenderStrategy mirror (src/RenderStrategy.h:12-26).  RenderSceneIntoPPM renders every camera of the scene and
+    writes `camera.image_name` as a P3 text PPM exactly like Image::SaveImageAsPPM (src/Image.cpp:54-77); the float HDR
+    frames stay available in `self.frames` (the reference only ever keeps the 8-bit image, Q20)."""
+
+    def __init__(self, device=0, seed=0, out_dir="."):
+        self.ctx = Context(device)
+        self.seed = seed
+        self.out_dir = out_dir
+        self.frames = {}
+        self.stats = {}
+
+    def RenderSceneIntoPPM(self, scene):
+        self.ctx.upload(scene)               # RetrieveRenderingParamsFromScene: builds the accelerator
+        for i, cam in enumerate(scene.cameras):
+            hdr, pid, pt, st = self.ctx.render(i, seed=self.seed, timing=1)
+            self.frames[cam["image_name"]] = hdr
+            self.stats[cam["image_name"]] = st
+            write_ppm(os.path.join(self.out_dir, cam["image_name"]), resolve_8bit(hdr))
+
+    def close(self):
+        self.ctx.close()
+
+
+def write_ppm(path, rgb8):
+    """Image::SaveImageAsPPM (src/Image.cpp:54-77): "P3\\n<w> <h>\\n255\\n", then per image row every channel as "%d "
+    and a newline."""
+    h, w, _ = rgb8.shape
+    with open(path, "w") as f:
+        f.write("P3\n%d %d\n255\n" % (w, h))
+        for y in range(h):
+            f.write("".join("%d " % v for v in rgb8[y].reshape(-1)))
+            f.write("\n")

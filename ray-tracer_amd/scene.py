@@ -527,7 +527,7 @@ def load_xml(path, scene_dir=None, texture_loader=None, perlin_tables=None):
         if cam.get("type") == "lookAt":
             b.add_lookat_camera(pos, _floats(txt(cam, "GazePoint")), up, float(txt(cam, "FovY")), dist, nx, ny, **kw)
         else:
-            b.add_camera(pos, _floats(txt(cam, "Gaze")), up, _floats(txt(cam, "NearPlane")), dist, nx, ny, **kw)
+            b.add_camera(pos, _floats(txt(cam, "Gaze"))[:3], up[:3], _floats(txt(cam, "NearPlane"))[:4], dist, nx, ny, **kw)
 
     # BRDFs: pushed category by category, looked up by push position (SceneParser.cpp:188-278, :380)
     brdfs = []
