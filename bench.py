@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the MI355X render hot path on BASELINE.json's config 2 (the ~1M-triangle "dragon" scene).
+
+A "step" is one frame: ray generation, closest-hit traversal, shadow rays, shading, reflect/refract recursion to
+depth 6, resolve into an HDR framebuffer that already lives in HBM (scene + BVH are uploaded before the timed region,
+like the reference's own Timer excludes the BVH build, src/DefaultRenderer.cpp:47-61).  One "ray" is one closest-hit
+query (the unit of AccelerationStructure::Intersect): primary + shadow + reflection + refraction.
+
+N > 1 (torchrun, one process per GPU): the frame is cut into interleaved 32x32 tiles, rank r renders tiles with
+id % N == r, and the HDR tiles are gathered on rank 0 over RCCL inside the timed region.  Scaling is WEAK: the image
+resolution grows with N (same camera frustum, more pixels) so that every GPU keeps the 800x480-pixel share of config 2.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+RAY_BYTES = 48                 # ray record read per query: origin+time, direction+medium, meta (3 x 16 B)
+HIT_BYTES = 64                 # hit record written per closest-hit query (4 x 16 B); a shadow query writes 4 B
+NODE_BYTES = 64                # one DevNode (both child boxes) per internal-node visit
+PRIM_BYTES = 64                # one DevPrim record per triangle / sphere test
+RES_BY_GPUS = {1: (800, 480), 2: (1600, 480), 4: (1600, 960), 8: (3200, 960)}
+TILE = 32
+
+
+def resolution_for(n_gpus):
+    if n_gpus in RES_BY_GPUS:
+        return RES_BY_GPUS[n_gpus]
+    return 800 * n_gpus, 480
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--tris", type=int, default=1_000_000, help="triangles of the stand-in mesh (config 2: 1M)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-row-step", type=int, default=16, help="CPU baseline renders every k-th row of the frame")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    rt = importlib.import_module("ray-tracer_amd")
+    synth = importlib.import_module("ray-tracer_amd.synth")
+    abi = rt.abi
+
+    nx, ny = resolution_for(world)
+    soup = synth.dragon_standin_scene(args.tris, nx, ny)
+    ctx = rt.Context(local_rank)
+    t0 = time.time()
+    ctx.upload(soup)
+    upload_s = time.time() - t0
+    cd = soup.camera_desc(0)
+
+    n_owned = ctx.L.rt_owned_pixel_count(nx, ny, TILE, rank, world)
+    counts = [ctx.L.rt_owned_pixel_count(nx, ny, TILE, r, world) for r in range(world)]
+    max_owned = max(counts)
+    tile_hdr = torch.zeros((max_owned, 3), dtype=torch.float32, device=dev)       # compact owned pixels, HBM resident
+    gathered = torch.zeros((world, max_owned, 3), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
+    frame = torch.zeros((ny * nx, 3), dtype=torch.float32, device=dev) if rank == 0 else None
+    orders = None
+    if rank == 0:
+        orders = [torch.from_numpy(rt.renderer.tile_pixel_order(nx, ny, TILE, r, world).astype(np.int64)).to(dev) for r in range(world)]
+
+    def step(opts, stats):
+        ctx.render_device(cd, opts, tile_hdr.data_ptr(), None, None, stats)       # returns after the stream is idle
+        if world > 1:
+            # the only exchange step of the path: HDR tiles -> rank 0; point-to-point gather over xGMI
+            dist.gather(tile_hdr, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+            if rank == 0:
+                for r in range(world):
+                    frame.index_copy_(0, orders[r], gathered[r, :counts[r]])
+        elif rank == 0:
+            frame.index_copy_(0, orders[0], tile_hdr[:counts[0]])
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    opts_count = ctx.make_opts(seed=0, tile_size=TILE, tile_rank=rank, tile_world=world, output_on_device=True, compact_output=True, timing=2)
+    opts_timed = ctx.make_opts(seed=0, tile_size=TILE, tile_rank=rank, tile_world=world, output_on_device=True, compact_output=True, timing=1)
+    st_count = abi.Stats()
+    step(opts_count, st_count)                      # untimed: per-frame traversal counters (deterministic)
+    for _ in range(args.warmup):
+        step(opts_timed, abi.Stats())
+    sync()
+    t0 = time.perf_counter()
+    st_steps = [abi.Stats() for _ in range(args.steps)]
+    for i in range(args.steps):
+        step(opts_timed, st_steps[i])
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    rays_rank = float(sum(st_steps[0].rays))
+    vals = torch.tensor([elapsed, rays_rank, sum(s.ms_trace for s in st_steps), sum(s.trace_launches for s in st_steps),
+                         float(st_count.node_visits), float(st_count.tri_tests), float(st_count.sphere_tests),
+                         float(sum(st_count.rays)), float(st_count.rays[abi.RT_RAY_SHADOW])], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = vals.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = vals.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0])
+        total_rays = float(sm[1])
+    else:
+        total_rays = rays_rank
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = total_rays / (elapsed / args.steps) / 1e6
+
+    # roofline of the dominant kernels (k_trace + k_trace_shadow), rank 0's launches: algorithmic bytes / HIP-event time
+    n_node, n_tri, n_sph = float(st_count.node_visits), float(st_count.tri_tests), float(st_count.sphere_tests)
+    n_rays = float(sum(st_count.rays))
+    n_shadow = float(st_count.rays[abi.RT_RAY_SHADOW])
+    frame_bytes = NODE_BYTES * n_node + PRIM_BYTES * (n_tri + n_sph) + RAY_BYTES * n_rays + HIT_BYTES * (n_rays - n_shadow) + 4 * n_shadow
+    launches = sum(s.trace_launches for s in st_steps) / args.steps
+    trace_ms = sum(s.ms_trace for s in st_steps) / args.steps
+    bytes_per_launch = frame_bytes / launches
+    avg_launch_ms = trace_ms / launches
+    achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_trace_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": traffic, "kernel": "k_trace+k_trace_shadow", "launches_per_frame": launches,
+                "avg_launch_ms": round(avg_launch_ms, 5), "algorithmic_bytes_per_launch": round(bytes_per_launch),
+                "per_ray": {"nodes": round(n_node / n_rays, 2), "tris": round(n_tri / n_rays, 2), "bytes": round(frame_bytes / n_rays, 1)},
+                "trace_ms_per_frame": round(trace_ms, 4)}
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import orc
+        osc = orc.OracleScene(soup)
+        cores = min(16, os.cpu_count() or 1)
+        t0 = time.perf_counter()
+        _, _, _, cst = osc.render(0, nthreads=cores, dynamic=True, row_step=args.cpu_row_step, want_ids=False)
+        cpu_s = time.perf_counter() - t0
+        cpu = {"value": round(sum(cst.rays) / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+               "sample": "every %dth row of the %dx%d frame (%d rows, %d rays, %.1f s), oracle/rt_oracle.cpp with %d threads, rows handed out dynamically"
+                         % (args.cpu_row_step, nx, ny, len(range(0, ny, args.cpu_row_step)), sum(cst.rays), cpu_s, cores)}
+        osc.close()
+
+    bvh = ctx.bvh_info()
+    out = {"metric": "Mrays/s (primary+secondary, whole node)", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "BASELINE config 2: other_dragon.xml camera/lights/materials, depth 6, 1 spp, stand-in %d-triangle mesh "
+                                  "(dragon_remeshed.ply is a missing blob) + mirror floor" % args.tris,
+                      "resolution": [nx, ny], "spp": 1, "rays_per_frame": int(total_rays), "tiles": "%dx%d interleaved over %d GPU(s)" % (TILE, TILE, world),
+                      "bvh_nodes": int(bvh.n_nodes), "bvh_depth": int(bvh.max_depth), "scene_upload_s": round(upload_s, 2)},
+           "roofline": roofline, "cpu_baseline": cpu}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -33,7 +33,7 @@ def lib():
         L.orc_scene_destroy.argtypes = [C.c_void_p]
         L.orc_bvh_info.argtypes = [C.c_void_p, C.POINTER(abi.BvhInfo)]
         L.orc_bvh_leaves.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.orc_render.argtypes = [C.c_void_p, C.POINTER(abi.CameraDesc), C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
+        L.orc_render.argtypes = [C.c_void_p, C.POINTER(abi.CameraDesc), C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(abi.Stats)]
         L.orc_intersect_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.orc_philox4x32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -80,7 +80,7 @@ class OracleScene:
         lib().orc_bvh_leaves(self.h, se.ctypes.data, order.ctypes.data, box.ctypes.data)
         return se, order, box
 
-    def render(self, cam=0, seed=0, nthreads=8, dynamic=False, rows=None, want_ids=True, **cam_override):
+    def render(self, cam=0, seed=0, nthreads=8, dynamic=False, rows=None, row_step=1, want_ids=True, **cam_override):
         cd = self.soup.camera_desc(cam, **cam_override) if not isinstance(cam, abi.CameraDesc) else cam
         nx, ny = cd.nx, cd.ny
         hdr = np.zeros((ny, nx, 3), np.float32)
@@ -88,7 +88,7 @@ class OracleScene:
         pt = np.zeros((ny, nx), np.float32) if want_ids else None
         st = abi.Stats()
         r0, r1 = (0, ny) if rows is None else rows
-        rc = lib().orc_render(self.h, C.byref(cd), seed, nthreads, int(dynamic), r0, r1, hdr.ctypes.data,
+        rc = lib().orc_render(self.h, C.byref(cd), seed, nthreads, int(dynamic), r0, r1, row_step, hdr.ctypes.data,
                               pid.ctypes.data if want_ids else None, pt.ctypes.data if want_ids else None, C.byref(st))
         if rc != 0:
             raise RuntimeError("orc_render rc=%d" % rc)

@@ -1372,12 +1372,14 @@ int orc_bvh_leaves(void *h, int64_t *leaf_start_end /*[2*n_leaves]*/, int32_t *p
 
 // Render rows [row0,row1) of the frame with `nthreads` threads.  dynamic == 0: contiguous row bands exactly like
 // DefaultRenderer::RenderCamera (rowDiff = rows / nthreads, last band takes the remainder, DefaultRenderer.cpp:65-75);
-// dynamic != 0: rows handed out one at a time (used for the all-cores baseline).
-int orc_render(void *h, const rt_camera_desc *cam, uint32_t seed, int nthreads, int dynamic, int row0, int row1,
+// dynamic != 0: rows handed out one at a time (used for the all-cores baseline).  row_step > 1 renders only every
+// row_step-th row of the range (bounded CPU-baseline samples); the other rows of the outputs are left untouched.
+int orc_render(void *h, const rt_camera_desc *cam, uint32_t seed, int nthreads, int dynamic, int row0, int row1, int row_step,
                float *hdr_rgb, int32_t *prim_id, float *prim_t, rt_stats *stats) {
     orc::Scene *sc = static_cast<orc::Scene *>(h);
     if (!sc || !cam || !hdr_rgb) return RT_ERR_INVALID;
     if (nthreads < 1) nthreads = 1;
+    if (row_step < 1) row_step = 1;
     orc::Camera camera(*cam);
     std::vector<orc::Counters> counters(nthreads);
     std::atomic<int> nextRow(row0);
@@ -1390,11 +1392,11 @@ int orc_render(void *h, const rt_camera_desc *cam, uint32_t seed, int nthreads, 
             }
         };
         if (dynamic) {
-            for (;;) { int row = nextRow.fetch_add(1); if (row >= row1) break; doRow(row); }
+            for (;;) { int row = nextRow.fetch_add(row_step); if (row >= row1) break; doRow(row); }
         } else {
             int rows = row1 - row0, rowDiff = rows / nthreads;
             int a = row0 + rowDiff * tid, b = (tid == nthreads - 1) ? row1 : row0 + rowDiff * (tid + 1);
-            for (int row = a; row < b; ++row) doRow(row);
+            for (int row = a; row < b; ++row) if ((row - row0) % row_step == 0) doRow(row);
         }
         counters[tid] = tr.cnt;
     };
