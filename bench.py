@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--tris", type=int, default=1_000_000, help="triangles of the stand-in mesh (config 2: 1M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-row-step", type=int, default=16, help="CPU baseline renders every k-th row of the frame")
+    ap.add_argument("--cpu-row-step", type=int, default=1, help="CPU baseline renders every k-th row of the frame")
     args = ap.parse_args()
 
     import torch
