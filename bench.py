@@ -78,26 +78,13 @@ def main():
     upload_s = time.time() - t0
     cd = soup.camera_desc(0)
 
-    n_owned = ctx.L.rt_owned_pixel_count(nx, ny, TILE, rank, world)
-    counts = [ctx.L.rt_owned_pixel_count(nx, ny, TILE, r, world) for r in range(world)]
-    max_owned = max(counts)
-    tile_hdr = torch.zeros((max_owned, 3), dtype=torch.float32, device=dev)       # compact owned pixels, HBM resident
-    gathered = torch.zeros((world, max_owned, 3), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
-    frame = torch.zeros((ny * nx, 3), dtype=torch.float32, device=dev) if rank == 0 else None
-    orders = None
-    if rank == 0:
-        orders = [torch.from_numpy(rt.renderer.tile_pixel_order(nx, ny, TILE, r, world).astype(np.int64)).to(dev) for r in range(world)]
+    mg = importlib.import_module("ray-tracer_amd.multigpu")
+    tg = mg.TileGather(nx, ny, TILE, rank, world, dev, torch)                    # compact owned pixels + frame, HBM resident
 
     def step(opts, stats):
-        ctx.render_device(cd, opts, tile_hdr.data_ptr(), None, None, stats)       # returns after the stream is idle
-        if world > 1:
-            # the only exchange step of the path: HDR tiles -> rank 0; point-to-point gather over xGMI
-            dist.gather(tile_hdr, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
-            if rank == 0:
-                for r in range(world):
-                    frame.index_copy_(0, orders[r], gathered[r, :counts[r]])
-        elif rank == 0:
-            frame.index_copy_(0, orders[0], tile_hdr[:counts[0]])
+        ctx.render_device(cd, opts, tg.tile_hdr.data_ptr(), None, None, stats)    # returns after the stream is idle
+        # the only exchange step of the path: HDR tiles -> rank 0; point-to-point gather over xGMI
+        tg.gather(dist)
 
     def sync():
         torch.cuda.synchronize()

@@ -1,0 +1,39 @@
+"""Tile-sharded frames over several ranks (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm).
+
+The render path has no data-path collective: every rank renders the interleaved tiles it owns (rt_render with
+tile_rank / tile_world, compact output).  The only exchange is the per-frame gather of the HDR tiles on rank 0 — the
+step that precedes tonemapping / file output in the reference (src/DefaultRenderer.cpp:78).  Disjoint tiles => a
+point-to-point gather (7 peers -> rank 0, one xGMI link each), not an all-reduce.
+"""
+import numpy as np
+
+from . import renderer
+
+
+class TileGather:
+    """Pre-computes the tile ownership of a frame and gathers / de-interleaves compact tile buffers on rank 0."""
+
+    def __init__(self, nx, ny, tile_size, rank, world, device, torch):
+        self.nx, self.ny, self.tile, self.rank, self.world = nx, ny, tile_size, rank, world
+        self.torch = torch
+        L = renderer.library()
+        self.counts = [int(L.rt_owned_pixel_count(nx, ny, tile_size, r, world)) for r in range(world)]
+        self.max_owned = max(self.counts)
+        self.tile_hdr = torch.zeros((self.max_owned, 3), dtype=torch.float32, device=device)
+        self.gathered = torch.zeros((world, self.max_owned, 3), dtype=torch.float32, device=device) if (world > 1 and rank == 0) else None
+        self.frame = torch.zeros((ny * nx, 3), dtype=torch.float32, device=device) if rank == 0 else None
+        self.orders = None
+        if rank == 0:
+            self.orders = [torch.from_numpy(renderer.tile_pixel_order(nx, ny, tile_size, r, world).astype(np.int64)).to(device)
+                           for r in range(world)]
+
+    def gather(self, dist=None):
+        """tile_hdr (this rank's compact pixels) -> rank 0's full frame [ny*nx, 3].  Returns the frame on rank 0."""
+        if self.world > 1:
+            dist.gather(self.tile_hdr, list(self.gathered.unbind(0)) if self.rank == 0 else None, dst=0)
+            if self.rank == 0:
+                for r in range(self.world):
+                    self.frame.index_copy_(0, self.orders[r], self.gathered[r, :self.counts[r]])
+        elif self.rank == 0:
+            self.frame.index_copy_(0, self.orders[0], self.tile_hdr[:self.counts[0]])
+        return self.frame

@@ -15,10 +15,12 @@ F32 = np.float32
 
 
 def torus_knot_mesh(n_tris=1_000_000, seed=7, extent=300.0, center=(0.0, 100.0, -20.0)):
-    """Closed tube around a (2,3) torus knot, `n_tris` triangles (must be 2*U*V with U = 2*V)."""
+    """Closed tube around a (2,3) torus knot, `n_tris` triangles (n_tris = 2*U*V, V the divisor nearest sqrt(n_tris/4))."""
     v_cnt = int(round((n_tris / 4) ** 0.5))
+    while v_cnt > 3 and n_tris % (2 * v_cnt):
+        v_cnt -= 1
     u_cnt = n_tris // (2 * v_cnt)
-    assert 2 * u_cnt * v_cnt == n_tris, "n_tris must factor as 2*U*V"
+    assert 2 * u_cnt * v_cnt == n_tris and v_cnt >= 3, "n_tris must factor as 2*U*V"
     rng = np.random.RandomState(seed)
     u = np.linspace(0.0, 2 * np.pi, u_cnt, endpoint=False)
     v = np.linspace(0.0, 2 * np.pi, v_cnt, endpoint=False)

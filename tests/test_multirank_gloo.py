@@ -1,0 +1,45 @@
+"""The N > 1 path on CPU: two gloo ranks own interleaved tiles, produce their compact tile buffers from the CPU oracle's
+frame of a scene, and rank 0 gathers + de-interleaves them into the full frame (ray-tracer_amd/multigpu.py, the same
+code bench.py runs over RCCL)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import importlib, os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, %r)
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    rt = importlib.import_module("ray-tracer_amd")
+    mg = importlib.import_module("ray-tracer_amd.multigpu")
+    from oracle import orc
+    soup = rt.SceneSoup.load(os.path.join(%r, "scenes", "cornellbox_recursive.npz"))
+    nx, ny, tile = 96, 80, 16
+    hdr, _, _, _ = orc.OracleScene(soup).render(0, nthreads=2, nx=nx, ny=ny, want_ids=False)
+    full = torch.from_numpy(hdr.reshape(-1, 3))
+    tg = mg.TileGather(nx, ny, tile, rank, world, torch.device("cpu"), torch)
+    own = torch.from_numpy(rt.renderer.tile_pixel_order(nx, ny, tile, rank, world).astype(np.int64))
+    assert len(own) == tg.counts[rank]
+    tg.tile_hdr[:len(own)] = full[own]            # what rt_render(compact_output=1) of this rank would have produced
+    frame = tg.gather(dist)
+    if rank == 0:
+        assert torch.equal(frame, full), "gathered frame differs"
+        assert sum(tg.counts) == nx * ny
+        print("GATHER_OK", tg.counts)
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+def test_two_rank_tile_gather(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % (ROOT, ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "GATHER_OK" in out.stdout
