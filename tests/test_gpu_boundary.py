@@ -1,0 +1,147 @@
+"""GPU tests of the two drop-in boundaries at BASELINE sizes: rt_intersect_batch (AccelerationStructure::Intersect) on
+random rays, the full config-2 frame (1M triangles) against the oracle, tile sharding, determinism, error paths."""
+import importlib
+
+import numpy as np
+import pytest
+
+from parity_util import compare_frames
+
+pytestmark = pytest.mark.gpu
+abi = importlib.import_module("ray-tracer_amd").abi
+synth = importlib.import_module("ray-tracer_amd.synth")
+
+
+def random_rays(n, seed, center, radius):
+    rng = np.random.RandomState(seed)
+    r = np.zeros(n, abi.ray_dtype)
+    o = rng.randn(n, 3)
+    o = o / np.linalg.norm(o, axis=1, keepdims=True) * radius * (1.0 + rng.rand(n, 1)) + center
+    tgt = center + (rng.rand(n, 3) - 0.5) * radius
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    # edge cases the reference tests implicitly: axis-aligned directions (d.x == 0 => never a hit, Q2), zero components
+    d[:64, 0] = 0.0
+    d[64:128, 1] = 0.0
+    d[128:192] = [0, 0, -1]
+    d[:192] /= np.maximum(np.linalg.norm(d[:192], axis=1, keepdims=True), 1e-30)
+    r["origin"], r["direction"], r["time"] = o.astype(np.float32), d.astype(np.float32), rng.rand(n).astype(np.float32)
+    return r
+
+
+@pytest.mark.parametrize("name,center,radius", [("scienceTree", (2, 2, 0), 6.0), ("cornellbox_boxes_dynamic", (0, 0, 0), 12.0),
+                                                ("spheres", (0, 0, 0), 8.0), ("bunny", (0, 0.1, 0), 0.3)])
+def test_intersect_batch(rt, orc, gpu_ctx, scene_path, name, center, radius):
+    soup = rt.SceneSoup.load(scene_path(name))
+    acc = rt.Mi355Accelerator(soup, context=gpu_ctx)
+    rays = random_rays(20000, 5, np.array(center, np.float64), radius)
+    g = acc.Intersect(rays)
+    c = orc.OracleScene(soup).intersect(rays)
+    assert np.array_equal(g["shape"], c["shape"])
+    hit = c["shape"] >= 0
+    assert hit.sum() > 500
+    assert np.array_equal(g["t"].view(np.uint32), c["t"].view(np.uint32))
+    assert np.array_equal(g["ip"][hit].view(np.uint32), c["ip"][hit].view(np.uint32))
+    assert np.array_equal(g["n"][hit].view(np.uint32), c["n"][hit].view(np.uint32))
+    sph = hit & ((c["shape"] & abi.RT_PRIM_SPHERE) != 0)
+    assert np.array_equal(g["uv"][hit & ~sph].view(np.uint32), c["uv"][hit & ~sph].view(np.uint32))
+    np.testing.assert_allclose(g["uv"][sph], c["uv"][sph], atol=2e-6)          # acosf / atan2f: last-ulp differences allowed
+    assert (g["shape"][:64] == -1).all()                                          # d.x == 0
+
+
+def test_empty_batch_and_empty_scene(rt, gpu_ctx):
+    b = rt.SceneBuilder()
+    b.add_material()
+    b.add_camera((0, 0, 5), (0, 0, -1), (0, 1, 0), (-1, 1, -1, 1), 1, 16, 8)
+    soup = b.finish()
+    soup.background = np.array([3, 4, 5], np.float32)
+    gpu_ctx.upload(soup)
+    assert len(gpu_ctx.intersect(np.zeros(0, abi.ray_dtype))) == 0
+    h = gpu_ctx.intersect(random_rays(256, 1, np.zeros(3), 3.0))
+    assert (h["shape"] == -1).all()
+    hdr, pid, pt, st = gpu_ctx.render(0)
+    assert (pid == -1).all() and np.allclose(hdr, [3, 4, 5])
+
+
+@pytest.fixture(scope="module")
+def dragon(rt, orc, gpu_ctx):
+    soup = synth.dragon_standin_scene(1_000_000, 800, 480)
+    osc = orc.OracleScene(soup)
+    c = osc.render(0, nthreads=16, dynamic=True)
+    osc.close()
+    return soup, c
+
+
+def test_config2_full_frame(rt, gpu_ctx, dragon):
+    """BASELINE config 2 at full size: 1M-triangle mesh + mirror floor, 800x480, depth 6 (9.3M rays)."""
+    soup, (c_hdr, c_id, c_t, c_st) = dragon
+    gpu_ctx.upload(soup)
+    g_hdr, g_id, g_t, g_st = gpu_ctx.render(0, timing=1)
+    m = compare_frames(g_hdr, c_hdr, g_id, c_id, g_t, c_t)
+    assert list(g_st.rays) == list(c_st.rays)
+    print("config2", m, list(g_st.rays), "kernels %.2f ms" % g_st.ms_kernels)
+    # determinism: a second frame is bit-identical (queue order is not, the result is)
+    h2, i2, t2, _ = gpu_ctx.render(0)
+    assert np.array_equal(h2.view(np.uint32), g_hdr.view(np.uint32)) and np.array_equal(i2, g_id)
+    # small batches (many wavefront batches per frame) give the same frame
+    h3, i3, _, _ = gpu_ctx.render(0, max_batch_samples=50000)
+    assert np.array_equal(h3.view(np.uint32), g_hdr.view(np.uint32)) and np.array_equal(i3, g_id)
+
+
+def test_config2_tile_sharding(rt, gpu_ctx, dragon):
+    """The frames of N tile ranks tile the full frame exactly (what 8 GPUs + the RCCL gather produce)."""
+    soup, (c_hdr, c_id, c_t, c_st) = dragon
+    gpu_ctx.upload(soup)
+    full, fid, _, fst = gpu_ctx.render(0)
+    for world in (2, 8):
+        acc = np.zeros_like(full)
+        ids = np.full_like(fid, -7)
+        rays = np.zeros(4, np.int64)
+        for rank in range(world):
+            h, i, _, st = gpu_ctx.render(0, tile_size=32, tile_rank=rank, tile_world=world, compact_output=True)
+            order = rt.renderer.tile_pixel_order(800, 480, 32, rank, world)
+            acc.reshape(-1, 3)[order] = h
+            ids.reshape(-1)[order] = i
+            rays += np.array(list(st.rays), np.int64)
+            # non-compact output of the same rank: owned pixels filled, the rest zero / -1
+            if rank == 1:
+                h2, i2, _, _ = gpu_ctx.render(0, tile_size=32, tile_rank=rank, tile_world=world)
+                mask = np.zeros(800 * 480, bool)
+                mask[order] = True
+                assert np.array_equal(h2.reshape(-1, 3)[mask].view(np.uint32), h.view(np.uint32))
+                assert (h2.reshape(-1, 3)[~mask] == 0).all() and (i2.reshape(-1)[~mask] == -1).all()
+        assert np.array_equal(acc.view(np.uint32), full.view(np.uint32))
+        assert np.array_equal(ids, fid)
+        assert rays.tolist() == list(fst.rays)
+
+
+def test_error_paths(rt, gpu_ctx, scene_path):
+    ctx = rt.Context(0)
+    with pytest.raises(rt.RtError) as e:
+        ctx.intersect(np.zeros(4, abi.ray_dtype))
+    assert e.value.code == abi.RT_ERR_NO_SCENE
+    soup = rt.SceneSoup.load(scene_path("simple"))
+    ctx.upload(soup)
+    with pytest.raises(rt.RtError) as e:
+        ctx.render(0, tile_size=16, tile_rank=5, tile_world=2)
+    assert e.value.code == abi.RT_ERR_INVALID
+    opts = ctx.make_opts()
+    opts.abi_version = 1
+    import ctypes as C
+    cd = soup.camera_desc(0)
+    hdr = np.zeros((cd.ny, cd.nx, 3), np.float32)
+    assert ctx.L.rt_render(ctx.h, C.byref(cd), C.byref(opts), hdr.ctypes.data, None, None, None) == abi.RT_ERR_ABI
+    ctx.close()
+
+
+def test_renderer_writes_ppm(rt, scene_path, tmp_path):
+    soup = rt.SceneSoup.load(scene_path("simple"))
+    soup.cameras[0]["nx"], soup.cameras[0]["ny"] = 40, 30
+    r = rt.Mi355Renderer(0, out_dir=str(tmp_path))
+    r.RenderSceneIntoPPM(soup)
+    name = soup.cameras[0]["image_name"]
+    toks = open(tmp_path / name).read().split()
+    assert toks[:4] == ["P3", "40", "30", "255"] and len(toks) == 4 + 40 * 30 * 3
+    img = np.array(toks[4:], np.int64).reshape(30, 40, 3)
+    assert np.array_equal(img, rt.renderer.resolve_8bit(r.frames[name]))
+    r.close()
