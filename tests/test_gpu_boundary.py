@@ -108,7 +108,7 @@ def test_config2_tile_sharding(rt, gpu_ctx, dragon):
                 h2, i2, _, _ = gpu_ctx.render(0, tile_size=32, tile_rank=rank, tile_world=world)
                 mask = np.zeros(800 * 480, bool)
                 mask[order] = True
-                assert np.array_equal(h2.reshape(-1, 3)[mask].view(np.uint32), h.view(np.uint32))
+                assert np.array_equal(h2.reshape(-1, 3)[order].view(np.uint32), h.view(np.uint32))
                 assert (h2.reshape(-1, 3)[~mask] == 0).all() and (i2.reshape(-1)[~mask] == -1).all()
         assert np.array_equal(acc.view(np.uint32), full.view(np.uint32))
         assert np.array_equal(ids, fid)
