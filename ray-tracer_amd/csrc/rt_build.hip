@@ -306,11 +306,13 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
     hs.params.bg_texture = d->bg_texture;
     hs.params.n_lights = d->n_lights; hs.params.n_materials = d->n_materials; hs.params.n_textures = d->n_textures;
     hs.params.bvh_depth = maxDepth;
+    hs.params.has_motion = 0;
+    for (const DevObject &o : hs.objects) if (o.flags & DEV_OBJ_MOTION) hs.params.has_motion = 1;
     float scale = 1.0f;
     if (!bn.empty())
         for (int k = 0; k < 3; ++k) scale = std::max(scale, std::max(std::fabs(hs.params.root_min[k]), std::fabs(hs.params.root_max[k])));
     hs.scene_scale = scale;
-    hs.params.prune_err = 2e-4f * scale;
+    hs.params.prune_err = (4.0f * d->isect_eps + 2e-4f) * scale;   // eps*edge slack of the Cramer test + float error
     hs.info.n_nodes = (int64_t)bn.size(); hs.info.n_leaves = (int64_t)hs.leaves.size(); hs.info.max_depth = maxDepth; hs.info._pad = 0;
     hs.info.n_leaf_prims = (int64_t)hs.prims.size();
     return RT_OK;

@@ -69,6 +69,7 @@ struct DevSceneParams {
     float root_min[3], root_max[3];
     float prune_err;          // absolute bound used to keep t-pruning conservative
     int32_t bvh_depth;
+    int32_t has_motion;       // any object with a non-zero motion-blur vector (selects the kernel instantiation)
 };
 #define RT_NO_ROOT 0x7fffffff
 

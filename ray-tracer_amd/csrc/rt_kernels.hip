@@ -67,16 +67,7 @@ struct ObjXf {     // per-lane cache of "the ray in the space of object `id`" (Q
     int id;
     int flags;     // DEV_OBJ_* of the object, DEV_OBJ_IDENTITY re-evaluated for motion-blurred objects
     f3 o, d;       // object-space ray
-    float M[12];   // xyz rows of the 4 columns of the object->world matrix in effect (T(blur*time)*M for moving objects)
 };
-
-__device__ __forceinline__ f3 obj_to_world_point(const float *M12, f3 p) {   // glm mat*vec4(p,1): (m0*x + m1*y) + (m2*z + m3*1)
-    f3 r;
-    r.x = (M12[0] * p.x + M12[3] * p.y) + (M12[6] * p.z + M12[9] * 1.0f);
-    r.y = (M12[1] * p.x + M12[4] * p.y) + (M12[7] * p.z + M12[10] * 1.0f);
-    r.z = (M12[2] * p.x + M12[5] * p.y) + (M12[8] * p.z + M12[11] * 1.0f);
-    return r;
-}
 
 // Matrices in effect for `ob` at ray time: M (object->world) and inv = inverse(transpose(M)).
 __device__ __forceinline__ void object_matrices(const DevObject &ob, float time, float *M, float *inv, int &flags) {
@@ -94,6 +85,7 @@ __device__ __forceinline__ void object_matrices(const DevObject &ob, float time,
     }
 }
 
+template <bool MOTION>
 __device__ __noinline__ void enter_object(const DevScene &sc, int obj, f3 o, f3 d, float time, ObjXf &x) {
     const DevObject &ob = sc.objects[obj];
     x.id = obj;
@@ -102,13 +94,31 @@ __device__ __noinline__ void enter_object(const DevScene &sc, int obj, f3 o, f3 
         x.o = o; x.d = d;
         return;
     }
-    float M[16], inv[16];
-    object_matrices(ob, time, M, inv, x.flags);
-    // Transform::operator()(Ray, obj2world=false): transpose(inv) * (o,1), transpose(inv) * (d,0), renormalise (acmath.h:1053-1069)
-    x.o = matT_mul_xyz(inv, o.x, o.y, o.z, 1.0f);
-    x.d = normalize3(matT_mul_xyz(inv, d.x, d.y, d.z, 0.0f));
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { x.M[c * 3 + 0] = M[c * 4 + 0]; x.M[c * 3 + 1] = M[c * 4 + 1]; x.M[c * 3 + 2] = M[c * 4 + 2]; }
+    if (!MOTION || !(ob.flags & DEV_OBJ_MOTION)) {
+        // Transform::operator()(Ray, obj2world=false): transpose(inv) * (o,1), transpose(inv) * (d,0), renormalise (acmath.h:1053-1069)
+        x.flags = ob.flags;
+        x.o = matT_mul_xyz(ob.inv, o.x, o.y, o.z, 1.0f);
+        x.d = normalize3(matT_mul_xyz(ob.inv, d.x, d.y, d.z, 0.0f));
+        return;
+    }
+    if (MOTION) {
+        float M[16], inv[16];
+        object_matrices(ob, time, M, inv, x.flags);
+        x.o = matT_mul_xyz(inv, o.x, o.y, o.z, 1.0f);
+        x.d = normalize3(matT_mul_xyz(inv, d.x, d.y, d.z, 0.0f));
+    }
+}
+
+// object -> world for a hit point of object `obj` (glm mat*vec4(p,1): (m0*x + m1*y) + (m2*z + m3*1)); the matrix is read
+// from the object table (static objects) or rebuilt for the ray's time (moving objects) — only hit candidates of
+// transformed objects come here.
+template <bool MOTION>
+__device__ __forceinline__ f3 object_point_to_world(const DevScene &sc, int obj, float time, f3 p) {
+    const DevObject &ob = sc.objects[obj];
+    if (!MOTION || !(ob.flags & DEV_OBJ_MOTION)) return mat_mul_xyz(ob.M, p.x, p.y, p.z, 1.0f);
+    float M[16];
+    mat_translate_mul(ld3(ob.mblur) * time, ob.M, M);
+    return mat_mul_xyz(M, p.x, p.y, p.z, 1.0f);
 }
 
 __device__ __forceinline__ float det3(float ax, float ay, float az, float bx, float by, float bz, float cx, float cy, float cz) {
@@ -117,7 +127,9 @@ __device__ __forceinline__ float det3(float ax, float ay, float az, float bx, fl
 }
 
 // Triangle::Intersect up to the world-space t (Triangle.cpp:115-135, 186-250; Q2, Q6, Q8)
-__device__ __forceinline__ bool hit_triangle(const float4 q0, const float4 q1, const float4 q2, const ObjXf &x, f3 wo, f3 wd, float eps, Cand &c) {
+template <bool MOTION>
+__device__ __forceinline__ bool hit_triangle(const DevScene &sc, const float4 q0, const float4 q1, const float4 q2, const ObjXf &x, float wox, float wdx,
+                                             float time, float eps, Cand &c) {
     const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
     const f3 d = x.d;
     const f3 pr = mk3(p0.x - x.o.x, p0.y - x.o.y, p0.z - x.o.z);
@@ -132,8 +144,8 @@ __device__ __forceinline__ bool hit_triangle(const float4 q0, const float4 q1, c
     const float t = det3(e1.x, e2.x, pr.x, e1.y, e2.y, pr.y, e1.z, e2.z, pr.z) * inv;
     if (!(t >= -eps)) return false;
     f3 ip = x.o + d * t;
-    if (!(x.flags & DEV_OBJ_IDENTITY)) ip = obj_to_world_point(x.M, ip);      // Triangle.cpp:296-298
-    c.t = (ip.x - wo.x) / wd.x;                                                // Ray::operator()(Vector3f), acmath.h:742
+    if (!(x.flags & DEV_OBJ_IDENTITY)) ip = object_point_to_world<MOTION>(sc, x.id, time, ip);      // Triangle.cpp:296-298
+    c.t = (ip.x - wox) / wdx;                                                  // Ray::operator()(Vector3f), acmath.h:742
     c.ip = ip; c.beta = beta; c.gamma = gamma;
     return true;
 }
@@ -151,51 +163,70 @@ __device__ __forceinline__ bool sphere_t(f3 center, float radius, f3 o, f3 d, fl
     t /= dd;
     return t > 0;
 }
-__device__ __forceinline__ bool hit_sphere(const float4 q0, const ObjXf &x, f3 wo, f3 wd, Cand &c) {
+template <bool MOTION>
+__device__ __forceinline__ bool hit_sphere(const DevScene &sc, const float4 q0, const ObjXf &x, float wox, float wdx, float time, Cand &c) {
     float t;
     if (!sphere_t(mk3(q0.x, q0.y, q0.z), q0.w, x.o, x.d, t)) return false;
-    f3 ip = obj_to_world_point(x.M, x.o + x.d * t);                           // Sphere.cpp:128 (no identity shortcut, Q9)
-    c.t = (ip.x - wo.x) / wd.x;
+    f3 ip = object_point_to_world<MOTION>(sc, x.id, time, x.o + x.d * t);             // Sphere.cpp:128 (no identity shortcut, Q9)
+    c.t = (ip.x - wox) / wdx;
     c.ip = ip; c.beta = 0; c.gamma = 0;
     return true;
 }
 
-// BoundingVolume3::Intersect (acmath.h:770-820, Q3) for one box, plus a conservative lower bound `lb` on the x-only t
-// of anything that can be hit inside the box (see DESIGN.md "pruning").
-__device__ __forceinline__ bool slab(f3 bmin, f3 bmax, f3 o, f3 d, f3 marg, float &tn_out, float &lb_out) {
-    float tn = 0, tf = FLT_MAX, lb;
+// BoundingVolume3::Intersect (acmath.h:770-820, Q3), exact form: true divisions, the reference's ternaries.
+__device__ __noinline__ bool slab_exact(f3 bmin, f3 bmax, f3 o, f3 d) {
+    float tn = 0, tf = FLT_MAX;
     float a = (bmin.x - o.x) / d.x, b = (bmax.x - o.x) / d.x;
     if (a > b) { float s = a; a = b; b = s; }
     tn = sel_max(tn, a); tf = sel_min(tf, b);
-    lb = a - marg.x;
     a = (bmin.y - o.y) / d.y; b = (bmax.y - o.y) / d.y;
     if (a > b) { float s = a; a = b; b = s; }
     tn = sel_max(tn, a); tf = sel_min(tf, b);
-    lb = sel_max(lb, a - marg.y);
     a = (bmin.z - o.z) / d.z; b = (bmax.z - o.z) / d.z;
     if (a > b) { float s = a; a = b; b = s; }
     tn = sel_max(tn, a); tf = sel_min(tf, b);
-    lb = sel_max(lb, a - marg.z);
-    lb = lb - marg.x;
-    lb = lb - fabsf(lb) * 1e-6f;
-    tn_out = tn; lb_out = lb;
     return !(tf < tn);
 }
 
-template <bool COUNT>
+// Fast form of the same test: multiplies by r = 1/d (computed once per ray with an IEEE division).  Every quotient is
+// within 2 ulp of the reference's, so the hit/miss decision is the reference's unless tn and tf are within ~1e-6
+// relative of each other; then (and for any NaN) the caller falls back to slab_exact.  Also returns the entry distance
+// (child ordering only) and a conservative lower bound `lb` on the x-only t of anything hit inside the box (pruning).
+//   returns 0 = miss, 1 = hit, 2 = undecided
+__device__ __forceinline__ int slab_fast(f3 bmin, f3 bmax, f3 o, f3 r, f3 marg, float &tn_out, float &lb_out) {
+    const float ax = (bmin.x - o.x) * r.x, bx = (bmax.x - o.x) * r.x;
+    const float ay = (bmin.y - o.y) * r.y, by = (bmax.y - o.y) * r.y;
+    const float az = (bmin.z - o.z) * r.z, bz = (bmax.z - o.z) * r.z;
+    const float nx = fminf(ax, bx), fx = fmaxf(ax, bx);
+    const float ny = fminf(ay, by), fy = fmaxf(ay, by);
+    const float nz = fminf(az, bz), fz = fmaxf(az, bz);
+    const float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
+    const float tf = fminf(fminf(fx, fy), fminf(fz, FLT_MAX));
+    float lb = fmaxf(fmaxf(nx - marg.x, ny - marg.y), nz - marg.z) - marg.x;
+    lb = lb - fabsf(lb) * 2e-6f;
+    tn_out = tn; lb_out = lb;
+    const float diff = tf - tn;
+    const float thr = 1e-6f * (fabsf(tf) + fabsf(tn));
+    if (!(fabsf(diff) > thr)) return 2;
+    return diff < 0.0f ? 0 : 1;
+}
+
+template <bool COUNT, bool MOTION>
 __device__ __forceinline__ void trace_closest(const DevScene &sc, f3 o, f3 d, float time, int *lds_col, int *ovf_col, int ovf_stride,
                                               Cand &best, int &best_leaf, unsigned &cnt_nodes, unsigned &cnt_boxes, unsigned &cnt_tris, unsigned &cnt_sph) {
     best.t = FLT_MAX; best.prim = -1; best.ip = mk3(0, 0, 0); best.beta = best.gamma = 0;
     best_leaf = -1;
     if (sc.p.root == RT_NO_ROOT) return;
+    // Q2: the hit parameter is (ip.x - o.x)/d.x; with d.x == 0 (or NaN) it is +-inf/NaN and no hit is ever accepted.
+    if (!(d.x != 0.0f)) { if (COUNT) ++cnt_boxes; return; }
     const float eps = sc.p.isect_eps;
-    const float err = sc.p.prune_err + 1e-3f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z)) * 0.2f;
-    const f3 marg = mk3(err / fabsf(d.x), err / fabsf(d.y), err / fabsf(d.z));
-    {
-        float tn, lb;
-        if (COUNT) ++cnt_boxes;
-        if (!slab(ld3(sc.p.root_min), ld3(sc.p.root_max), o, d, marg, tn, lb)) return;
-    }
+    const f3 r = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    // rays with a zero / denormal-range direction component take the exact slab test everywhere (inf and NaN quotients)
+    const bool exact_only = !(fabsf(d.y) > 1e-30f && fabsf(d.z) > 1e-30f && fabsf(d.x) > 1e-30f);
+    const float err = sc.p.prune_err + 2e-4f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z));
+    const f3 marg = mk3(err * fabsf(r.x) * 1.000001f, err * fabsf(r.y) * 1.000001f, err * fabsf(r.z) * 1.000001f);
+    if (COUNT) ++cnt_boxes;
+    if (!slab_exact(ld3(sc.p.root_min), ld3(sc.p.root_max), o, d)) return;
     const float4 *nodes4 = reinterpret_cast<const float4 *>(sc.nodes);
     const float4 *prims4 = reinterpret_cast<const float4 *>(sc.prims);
     ObjXf xf;
@@ -206,11 +237,14 @@ __device__ __forceinline__ void trace_closest(const DevScene &sc, f3 o, f3 d, fl
         if (cur >= 0) {
             const float4 n0 = nodes4[cur * 4 + 0], n1 = nodes4[cur * 4 + 1], n2 = nodes4[cur * 4 + 2], n3 = nodes4[cur * 4 + 3];
             float tnl, tnr, lbl, lbr;
-            bool hl = slab(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, d, marg, tnl, lbl);
-            bool hr = slab(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, d, marg, tnr, lbr);
+            int sl = slab_fast(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, r, marg, tnl, lbl);
+            int sr = slab_fast(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, r, marg, tnr, lbr);
+            if (exact_only) { sl = 2; sr = 2; lbl = lbr = -FLT_MAX; }
+            if (sl == 2) sl = slab_exact(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, d) ? 1 : 0;
+            if (sr == 2) sr = slab_exact(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, d) ? 1 : 0;
             if (COUNT) { ++cnt_nodes; cnt_boxes += 2; }
-            hl = hl && !(lbl > best.t);
-            hr = hr && !(lbr > best.t);
+            const bool hl = sl != 0 && !(lbl > best.t);
+            const bool hr = sr != 0 && !(lbr > best.t);
             const int left = __float_as_int(n3.x), right = __float_as_int(n3.y);
             if (hl && hr) {
                 int nearc = left, farc = right;
@@ -228,18 +262,18 @@ __device__ __forceinline__ void trace_closest(const DevScene &sc, f3 o, f3 d, fl
             Cand local;
             local.t = FLT_MAX; local.prim = -1; local.ip = mk3(0, 0, 0); local.beta = local.gamma = 0;
             for (int i = lf.start; i < lf.start + lf.count; ++i) {
-                const float4 q0 = prims4[i * 4 + 0], q3 = prims4[i * 4 + 3];
+                const float4 q3 = prims4[i * 4 + 3], q0 = prims4[i * 4 + 0];
                 const int obj = __float_as_int(q3.x), kind = __float_as_int(q3.z);
-                if (obj != xf.id) enter_object(sc, obj, o, d, time, xf);
+                if (obj != xf.id) enter_object<MOTION>(sc, obj, o, d, time, xf);
                 Cand c;
                 bool ok;
                 if (kind == DEV_PRIM_TRIANGLE) {
                     const float4 q1 = prims4[i * 4 + 1], q2 = prims4[i * 4 + 2];
                     if (COUNT) ++cnt_tris;
-                    ok = hit_triangle(q0, q1, q2, xf, o, d, eps, c);
+                    ok = hit_triangle<MOTION>(sc, q0, q1, q2, xf, o.x, d.x, time, eps, c);
                 } else {
                     if (COUNT) ++cnt_sph;
-                    ok = hit_sphere(q0, xf, o, d, c);
+                    ok = hit_sphere<MOTION>(sc, q0, xf, o.x, d.x, time, c);
                 }
                 if (ok && c.t > 0 && c.t < local.t - 0.001f) { local = c; local.prim = i; }
             }
@@ -313,7 +347,10 @@ __device__ __forceinline__ void flush_counters(DevCounters *counters, unsigned n
     }
 }
 
-template <bool COUNT>
+// Raw closest-hit record written by k_trace and completed by k_shade_pre (finalize_hit needs acosf/atan2f/inverse code
+// that would otherwise set the register allocation of the traversal kernel):
+//   hit0 = (t, prim record | -1, beta, gamma)   hit1 = (ip.xyz, unused)
+template <bool COUNT, bool MOTION>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(DevScene sc, LevelBuf lv, int n, int *ovf, int ovf_stride, DevCounters *counters) {
     __shared__ int s_stack[LDS_STACK * TRACE_BLOCK];
     const int gtid = blockIdx.x * TRACE_BLOCK + threadIdx.x;
@@ -323,20 +360,16 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(DevScene sc, LevelBuf lv,
         const float4 ro = lv.ray_o[i], rd = lv.ray_d[i];
         const f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
         Cand best; int leaf;
-        trace_closest<COUNT>(sc, o, d, ro.w, s_stack + threadIdx.x, ovf + gtid, ovf_stride, best, leaf, cn, cb, ct, cs);
-        HitOut h;
-        finalize_hit(sc, o, d, ro.w, best, h);
-        lv.hit0[i] = make_float4(h.t, __int_as_float(h.shape), __int_as_float(h.object), __int_as_float(h.prim));
-        lv.hit1[i] = make_float4(h.ip.x, h.ip.y, h.ip.z, h.n.x);
-        lv.hit2[i] = make_float4(h.n.y, h.n.z, h.u, h.v);
-        lv.hit3[i] = make_float4(h.theta, h.phi, 0.0f, 0.0f);
+        trace_closest<COUNT, MOTION>(sc, o, d, ro.w, s_stack + threadIdx.x, ovf + gtid, ovf_stride, best, leaf, cn, cb, ct, cs);
+        lv.hit0[i] = make_float4(best.t, __int_as_float(best.prim), best.beta, best.gamma);
+        lv.hit1[i] = make_float4(best.ip.x, best.ip.y, best.ip.z, 0.0f);
     }
     flush_counters<COUNT>(counters, cn, cb, ct, cs);
 }
 
 // Shadow rays (Q7): a full closest-hit query, then the distance window test of
 // LightContributionCalculator::IsThereAnObjectBetweenLightAndIntersectionPoint (:130-145).
-template <bool COUNT>
+template <bool COUNT, bool MOTION>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow(DevScene sc, ShadowBuf sb, int n, int *ovf, int ovf_stride, DevCounters *counters) {
     __shared__ int s_stack[LDS_STACK * TRACE_BLOCK];
     const int gtid = blockIdx.x * TRACE_BLOCK + threadIdx.x;
@@ -348,7 +381,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow(DevScene sc, Shado
         const float4 ro = sb.o[i], rd = sb.d[i];
         const f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
         Cand best; int leaf;
-        trace_closest<COUNT>(sc, o, d, ro.w, s_stack + threadIdx.x, ovf + gtid, ovf_stride, best, leaf, cn, cb, ct, cs);
+        trace_closest<COUNT, MOTION>(sc, o, d, ro.w, s_stack + threadIdx.x, ovf + gtid, ovf_stride, best, leaf, cn, cb, ct, cs);
         int occ = 0;
         if (best.prim >= 0) {
             const float dist = norm3(best.ip - mk3(ref.x, ref.y, ref.z));
@@ -360,8 +393,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow(DevScene sc, Shado
     flush_counters<COUNT>(counters, cn, cb, ct, cs);
 }
 
-// rt_intersect_batch: AccelerationStructure::Intersect for n independent rays
-template <bool COUNT>
+// rt_intersect_batch: AccelerationStructure::Intersect for n independent rays (traversal, then k_finalize_batch)
+template <bool COUNT, bool MOTION>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_batch(DevScene sc, const rt_ray *rays, rt_hit *hits, int n, int *ovf, int ovf_stride, DevCounters *counters) {
     __shared__ int s_stack[LDS_STACK * TRACE_BLOCK];
     const int gtid = blockIdx.x * TRACE_BLOCK + threadIdx.x;
@@ -371,17 +404,31 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_batch(DevScene sc, const 
         const rt_ray r = rays[i];
         const f3 o = ld3(r.origin), d = ld3(r.direction);
         Cand best; int leaf;
-        trace_closest<COUNT>(sc, o, d, r.time, s_stack + threadIdx.x, ovf + gtid, ovf_stride, best, leaf, cn, cb, ct, cs);
-        HitOut h;
-        finalize_hit(sc, o, d, r.time, best, h);
-        rt_hit out;
-        out.t = h.t; out.shape = h.shape;
-        out.ip[0] = h.ip.x; out.ip[1] = h.ip.y; out.ip[2] = h.ip.z;
-        out.n[0] = h.n.x; out.n[1] = h.n.y; out.n[2] = h.n.z;
-        out.uv[0] = h.u; out.uv[1] = h.v;
+        trace_closest<COUNT, MOTION>(sc, o, d, r.time, s_stack + threadIdx.x, ovf + gtid, ovf_stride, best, leaf, cn, cb, ct, cs);
+        rt_hit out;                      // raw form: shape = prim record, uv = (beta, gamma); completed by k_finalize_batch
+        out.t = best.t; out.shape = best.prim;
+        out.ip[0] = best.ip.x; out.ip[1] = best.ip.y; out.ip[2] = best.ip.z;
+        out.n[0] = out.n[1] = out.n[2] = 0.0f;
+        out.uv[0] = best.beta; out.uv[1] = best.gamma;
         hits[i] = out;
     }
     flush_counters<COUNT>(counters, cn, cb, ct, cs);
+}
+__global__ __launch_bounds__(256) void k_finalize_batch(DevScene sc, const rt_ray *rays, rt_hit *hits, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const rt_ray r = rays[i];
+    rt_hit raw = hits[i];
+    Cand best;
+    best.t = raw.t; best.prim = raw.shape; best.ip = ld3(raw.ip); best.beta = raw.uv[0]; best.gamma = raw.uv[1];
+    HitOut h;
+    finalize_hit(sc, ld3(r.origin), ld3(r.direction), r.time, best, h);
+    rt_hit out;
+    out.t = h.t; out.shape = h.shape;
+    out.ip[0] = h.ip.x; out.ip[1] = h.ip.y; out.ip[2] = h.ip.z;
+    out.n[0] = h.n.x; out.n[1] = h.n.y; out.n[2] = h.n.z;
+    out.uv[0] = h.u; out.uv[1] = h.v;
+    hits[i] = out;
 }
 
 static int trace_blocks(int n) {
@@ -389,23 +436,31 @@ static int trace_blocks(int n) {
     int cap = NUM_CUS * TRACE_BLOCKS_PER_CU;
     return want < cap ? (want < 1 ? 1 : want) : cap;
 }
+#define TRACE_DISPATCH(KERNEL, ...)                                                                                        \
+    do {                                                                                                                   \
+        const dim3 g(trace_blocks(n)), b(TRACE_BLOCK);                                                                     \
+        const bool cnt = counters != nullptr, mot = sc.p.has_motion != 0;                                                  \
+        if (cnt && mot) hipLaunchKernelGGL((KERNEL<true, true>), g, b, 0, s, __VA_ARGS__);                                 \
+        else if (cnt) hipLaunchKernelGGL((KERNEL<true, false>), g, b, 0, s, __VA_ARGS__);                                  \
+        else if (mot) hipLaunchKernelGGL((KERNEL<false, true>), g, b, 0, s, __VA_ARGS__);                                  \
+        else hipLaunchKernelGGL((KERNEL<false, false>), g, b, 0, s, __VA_ARGS__);                                          \
+    } while (0)
+
 void rt_launch_trace(hipStream_t s, const DevScene &sc, LevelBuf lv, int n, int *ovf, int ovf_depth, DevCounters *counters) {
     (void)ovf_depth;
     if (n <= 0) return;
-    if (counters) hipLaunchKernelGGL(k_trace<true>, dim3(trace_blocks(n)), dim3(TRACE_BLOCK), 0, s, sc, lv, n, ovf, rt_trace_grid_threads(), counters);
-    else hipLaunchKernelGGL(k_trace<false>, dim3(trace_blocks(n)), dim3(TRACE_BLOCK), 0, s, sc, lv, n, ovf, rt_trace_grid_threads(), counters);
+    TRACE_DISPATCH(k_trace, sc, lv, n, ovf, rt_trace_grid_threads(), counters);
 }
 void rt_launch_trace_shadow(hipStream_t s, const DevScene &sc, ShadowBuf sb, int n, int *ovf, int ovf_depth, DevCounters *counters) {
     (void)ovf_depth;
     if (n <= 0) return;
-    if (counters) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(trace_blocks(n)), dim3(TRACE_BLOCK), 0, s, sc, sb, n, ovf, rt_trace_grid_threads(), counters);
-    else hipLaunchKernelGGL(k_trace_shadow<false>, dim3(trace_blocks(n)), dim3(TRACE_BLOCK), 0, s, sc, sb, n, ovf, rt_trace_grid_threads(), counters);
+    TRACE_DISPATCH(k_trace_shadow, sc, sb, n, ovf, rt_trace_grid_threads(), counters);
 }
 void rt_launch_trace_batch(hipStream_t s, const DevScene &sc, const rt_ray *rays, rt_hit *hits, int n, int *ovf, int ovf_depth, DevCounters *counters) {
     (void)ovf_depth;
     if (n <= 0) return;
-    if (counters) hipLaunchKernelGGL(k_trace_batch<true>, dim3(trace_blocks(n)), dim3(TRACE_BLOCK), 0, s, sc, rays, hits, n, ovf, rt_trace_grid_threads(), counters);
-    else hipLaunchKernelGGL(k_trace_batch<false>, dim3(trace_blocks(n)), dim3(TRACE_BLOCK), 0, s, sc, rays, hits, n, ovf, rt_trace_grid_threads(), counters);
+    TRACE_DISPATCH(k_trace_batch, sc, rays, hits, n, ovf, rt_trace_grid_threads(), counters);
+    hipLaunchKernelGGL(k_finalize_batch, dim3((n + 255) / 256), dim3(256), 0, s, sc, rays, hits, n);
 }
 
 // ====================================================================================================
@@ -728,11 +783,22 @@ __global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, L
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int nl = sc.p.n_lights;
-    float t;
-    Surf s = load_surf(lv, i, t);
     const int4 meta = lv.ray_m[i];
-    bool lit = s.shape >= 0 || s.object >= 0;
-    lit = s.object >= 0;
+    const float4 ray_o = lv.ray_o[i], ray_d = lv.ray_d[i];
+    Surf s;
+    {   // complete the raw record k_trace left (what Triangle::Intersect / Sphere::Intersect return for the winner)
+        const float4 r0 = lv.hit0[i], r1 = lv.hit1[i];
+        Cand best;
+        best.t = r0.x; best.prim = __float_as_int(r0.y); best.beta = r0.z; best.gamma = r0.w; best.ip = mk3(r1.x, r1.y, r1.z);
+        HitOut h;
+        finalize_hit(sc, mk3(ray_o.x, ray_o.y, ray_o.z), mk3(ray_d.x, ray_d.y, ray_d.z), ray_o.w, best, h);
+        lv.hit0[i] = make_float4(h.t, __int_as_float(h.shape), __int_as_float(h.object), __int_as_float(h.prim));
+        lv.hit1[i] = make_float4(h.ip.x, h.ip.y, h.ip.z, h.n.x);
+        lv.hit2[i] = make_float4(h.n.y, h.n.z, h.u, h.v);
+        lv.hit3[i] = make_float4(h.theta, h.phi, 0.0f, 0.0f);
+        s.ip = h.ip; s.n = h.n; s.u = h.u; s.v = h.v; s.theta = h.theta; s.phi = h.phi; s.shape = h.shape; s.object = h.object; s.prim = h.prim;
+    }
+    bool lit = s.object >= 0;
     if (lit) {
         const DevObject &ob = sc.objects[s.object];
         if (replaces_all(sc, ob)) lit = false;                         // LightContributionCalculator.cpp:54-55
@@ -747,7 +813,7 @@ __global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, L
             if (meta.w >= 0 && meta.w == s.object) lit = false;        // IsInternalReflection (Q26)
         }
     }
-    const float time = lv.ray_o[i].w;
+    const float time = ray_o.w;
     for (int l = 0; l < nl; ++l) {
         const int k = i * nl + l;
         if (!lit) { sb.ipref[k] = make_float4(0, 0, 0, 0); continue; }
