@@ -325,7 +325,7 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
     }
 
     if ((int)c->levels.size() < max_depth + 2) c->levels.resize(max_depth + 2);
-    HIP_TRY(c, c->d_counts.ensure((size_t)max_depth + 2));
+    HIP_TRY(c, c->d_counts.ensure(3 * ((size_t)max_depth + 2)));
     HIP_TRY(c, c->d_kind.ensure(RT_RAY_KINDS));
     HIP_TRY(c, hipMemsetAsync(c->d_kind.p, 0, RT_RAY_KINDS * sizeof(unsigned long long), s));
     DevCounters *d_counters = nullptr;
@@ -364,14 +364,15 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
         HIP_TRY(c, c->levels[0].ensure((size_t)n0));
         c->levels[0].count = n0;
         rt_launch_raygen(s, dc, c->d_pixels.p, (int)p0, n0, c->levels[0].view());
-        HIP_TRY(c, hipMemsetAsync(c->d_counts.p, 0, ((size_t)max_depth + 2) * sizeof(int), s));
+        HIP_TRY(c, hipMemsetAsync(c->d_counts.p, 0, 3 * ((size_t)max_depth + 2) * sizeof(int), s));
+        int *fetch_closest = c->d_counts.p + (max_depth + 2), *fetch_shadow = c->d_counts.p + 2 * (max_depth + 2);
         int last = 0;
         for (int k = 0; k <= max_depth; ++k) {
             LevelMem &lm = c->levels[k];
             const int n = lm.count;
             if (n == 0) break;
             last = k;
-            int rc = timed_trace([&] { rt_launch_trace(s, c->dev, lm.view(), n, c->d_overflow.p, c->overflow_depth, d_counters); });
+            int rc = timed_trace([&] { rt_launch_trace(s, c->dev, lm.view(), n, fetch_closest + k, c->d_overflow.p, d_counters); });
             if (rc != RT_OK) return rc;
             ++trace_launches; trace_rays += (uint64_t)n;
             const size_t nsh = (size_t)n * (size_t)std::max(1, nl);
@@ -381,7 +382,7 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
             sb.o = c->sh_o.p; sb.d = c->sh_d.p; sb.ipref = c->sh_ip.p; sb.occluded = c->sh_occ.p; sb.capacity = (int)std::min<size_t>(c->sh_o.cap, 0x7fffffff);
             rt_launch_shade_pre(s, c->dev, dc, lm.view(), n, sb);
             if (nl > 0) {
-                rc = timed_trace([&] { rt_launch_trace_shadow(s, c->dev, sb, n * nl, c->d_overflow.p, c->overflow_depth, d_counters); });
+                rc = timed_trace([&] { rt_launch_trace_shadow(s, c->dev, sb, n * nl, fetch_shadow + k, c->d_overflow.p, d_counters); });
                 if (rc != RT_OK) return rc;
                 ++trace_launches; trace_rays += (uint64_t)n * nl;
             }
@@ -463,7 +464,9 @@ int rt_intersect_batch(rt_ctx *c, const rt_ray *rays, size_t n, rt_hit *hits, in
     }
     hipEvent_t a = nullptr, b = nullptr;
     if (stats) { HIP_TRY(c, hipEventCreate(&a)); HIP_TRY(c, hipEventCreate(&b)); HIP_TRY(c, hipEventRecord(a, s)); }
-    rt_launch_trace_batch(s, c->dev, dr, dh, (int)n, c->d_overflow.p, c->overflow_depth, d_counters);
+    HIP_TRY(c, c->d_counts.ensure(4));
+    HIP_TRY(c, hipMemsetAsync(c->d_counts.p, 0, sizeof(int), s));
+    rt_launch_trace_batch(s, c->dev, dr, dh, (int)n, c->d_counts.p, c->d_overflow.p, d_counters);
     if (stats) HIP_TRY(c, hipEventRecord(b, s));
     if (!on_device && n) HIP_TRY(c, hipMemcpyAsync(hits, c->d_hits.p, n * sizeof(rt_hit), hipMemcpyDeviceToHost, s));
     DevCounters hc;

@@ -211,51 +211,112 @@ __device__ __forceinline__ int slab_fast(f3 bmin, f3 bmax, f3 o, f3 r, f3 marg, 
     return diff < 0.0f ? 0 : 1;
 }
 
-template <bool COUNT, bool MOTION>
-__device__ __forceinline__ void trace_closest(const DevScene &sc, f3 o, f3 d, float time, int *lds_col, int *ovf_col, int ovf_stride,
-                                              Cand &best, int &best_leaf, unsigned &cnt_nodes, unsigned &cnt_boxes, unsigned &cnt_tris, unsigned &cnt_sph) {
-    best.t = FLT_MAX; best.prim = -1; best.ip = mk3(0, 0, 0); best.beta = best.gamma = 0;
-    best_leaf = -1;
-    if (sc.p.root == RT_NO_ROOT) return;
-    // Q2: the hit parameter is (ip.x - o.x)/d.x; with d.x == 0 (or NaN) it is +-inf/NaN and no hit is ever accepted.
-    if (!(d.x != 0.0f)) { if (COUNT) ++cnt_boxes; return; }
-    const float eps = sc.p.isect_eps;
-    const f3 r = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    // rays with a zero / denormal-range direction component take the exact slab test everywhere (inf and NaN quotients)
-    const bool exact_only = !(fabsf(d.y) > 1e-30f && fabsf(d.z) > 1e-30f && fabsf(d.x) > 1e-30f);
-    const float err = sc.p.prune_err + 2e-4f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z));
-    const f3 marg = mk3(err * fabsf(r.x) * 1.000001f, err * fabsf(r.y) * 1.000001f, err * fabsf(r.z) * 1.000001f);
-    if (COUNT) ++cnt_boxes;
-    if (!slab_exact(ld3(sc.p.root_min), ld3(sc.p.root_max), o, d)) return;
+// ----------------------------------------------------------------------------------------------------
+// Persistent wave64 traversal with per-lane ray refill.
+//
+// Rays differ wildly in traversal length (config 2: mean 49 nodes, tail > 500).  With one ray per lane per pass a wave
+// runs as long as its slowest lane: rocprof showed 7-14 % of VALU lanes active.  Here a wave is a persistent worker:
+// whenever lanes are idle it reserves that many ray indices from a global counter (one atomic per wave, __ballot +
+// __popcll prefix) and the idle lanes start new rays while the others continue.  The loop alternates a NODE phase
+// (lanes sitting on an internal node step; lanes that reached a leaf wait) and a LEAF phase (all lanes on a leaf run the
+// primitive tests together), so the long leaf code is executed with many lanes active ("while-while").
+//
+// IO policy: load(i, o, d, time) -> false when slot i needs no traversal (result already written);
+//            store(sc, i, best)   writes the result of ray i.
+// ----------------------------------------------------------------------------------------------------
+#define CUR_DONE 0x7ffffffe      // lane finished its ray (stack empty)
+#define NODE_PHASE_MIN_LANES 12  // leave the node phase when fewer lanes than this still sit on internal nodes
+
+template <bool COUNT, bool MOTION, class IO>
+__device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io, int n, int *fetch_counter, int *lds_col, int *ovf_col,
+                                                 int ovf_stride, unsigned &cnt_nodes, unsigned &cnt_boxes, unsigned &cnt_tris, unsigned &cnt_sph) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const float4 *nodes4 = reinterpret_cast<const float4 *>(sc.nodes);
     const float4 *prims4 = reinterpret_cast<const float4 *>(sc.prims);
+    const float eps = sc.p.isect_eps;
+    const bool no_scene = sc.p.root == RT_NO_ROOT;
+
+    bool has_ray = false, exact_only = false;
+    int ray_idx = 0, sp = 0, cur = CUR_DONE, best_leaf = -1;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), r = mk3(0, 0, 1), marg = mk3(0, 0, 0);
+    float time = 0;
+    Cand best;
+    best.t = FLT_MAX; best.prim = -1; best.ip = mk3(0, 0, 0); best.beta = best.gamma = 0;
     ObjXf xf;
     xf.id = -2; xf.flags = 0; xf.o = o; xf.d = d;
-    int sp = 0;
-    int cur = sc.p.root;
+    bool exhausted = false;          // wave-uniform: the global queue has no more rays
+
     for (;;) {
-        if (cur >= 0) {
-            const float4 n0 = nodes4[cur * 4 + 0], n1 = nodes4[cur * 4 + 1], n2 = nodes4[cur * 4 + 2], n3 = nodes4[cur * 4 + 3];
-            float tnl, tnr, lbl, lbr;
-            int sl = slab_fast(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, r, marg, tnl, lbl);
-            int sr = slab_fast(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, r, marg, tnr, lbr);
-            if (exact_only) { sl = 2; sr = 2; lbl = lbr = -FLT_MAX; }
-            if (sl == 2) sl = slab_exact(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, d) ? 1 : 0;
-            if (sr == 2) sr = slab_exact(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, d) ? 1 : 0;
-            if (COUNT) { ++cnt_nodes; cnt_boxes += 2; }
-            const bool hl = sl != 0 && !(lbl > best.t);
-            const bool hr = sr != 0 && !(lbr > best.t);
-            const int left = __float_as_int(n3.x), right = __float_as_int(n3.y);
-            if (hl && hr) {
-                int nearc = left, farc = right;
-                if (tnr < tnl) { nearc = right; farc = left; }
-                if (sp < LDS_STACK) lds_col[sp * TRACE_BLOCK] = farc; else ovf_col[(sp - LDS_STACK) * ovf_stride] = farc;
-                ++sp;
-                cur = nearc;
-                continue;
-            } else if (hl) { cur = left; continue; }
-            else if (hr) { cur = right; continue; }
-        } else {
+        // ---------------- refill idle lanes ----------------
+        if (!exhausted) {
+            const unsigned long long idle = __ballot(!has_ray);
+            if (idle) {
+                const int want = __popcll(idle);
+                int base = 0;
+                if (lane == __ffsll((long long)idle) - 1) base = atomicAdd(fetch_counter, want);
+                base = __shfl(base, __ffsll((long long)idle) - 1);
+                if (base + want >= n) exhausted = true;
+                if (!has_ray) {
+                    const int mine = base + __popcll(idle & lt_mask);
+                    if (mine < n && io.load(mine, o, d, time)) {
+                        ray_idx = mine;
+                        best.t = FLT_MAX; best.prim = -1; best.ip = mk3(0, 0, 0); best.beta = best.gamma = 0;
+                        best_leaf = -1; sp = 0; xf.id = -2;
+                        // Q2: the hit parameter is (ip.x - o.x)/d.x; with d.x == 0 (or NaN) no hit is ever accepted.
+                        bool alive = !no_scene && (d.x != 0.0f);
+                        if (COUNT) ++cnt_boxes;
+                        if (alive) alive = slab_exact(ld3(sc.p.root_min), ld3(sc.p.root_max), o, d);
+                        if (alive) {
+                            r = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                            // a zero / denormal-range direction component: exact slab test everywhere (inf and NaN quotients)
+                            exact_only = !(fabsf(d.y) > 1e-30f && fabsf(d.z) > 1e-30f && fabsf(d.x) > 1e-30f);
+                            const float err = sc.p.prune_err + 2e-4f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z));
+                            marg = mk3(err * fabsf(r.x) * 1.000001f, err * fabsf(r.y) * 1.000001f, err * fabsf(r.z) * 1.000001f);
+                            cur = sc.p.root;
+                            has_ray = true;
+                        } else {
+                            io.store(sc, mine, best);
+                        }
+                    }
+                }
+            }
+        }
+        if (!__any(has_ray)) { if (exhausted) break; else continue; }
+
+        // ---------------- node phase ----------------
+        for (;;) {
+            const bool at_node = has_ray && cur >= 0 && cur != CUR_DONE;
+            const unsigned long long m = __ballot(at_node);
+            if (m == 0) break;
+            if (__popcll(m) < NODE_PHASE_MIN_LANES && __any(has_ray && cur < 0)) break;   // enough leaf work is waiting
+            if (at_node) {
+                const float4 n0 = nodes4[cur * 4 + 0], n1 = nodes4[cur * 4 + 1], n2 = nodes4[cur * 4 + 2], n3 = nodes4[cur * 4 + 3];
+                float tnl, tnr, lbl, lbr;
+                int sl = slab_fast(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, r, marg, tnl, lbl);
+                int sr = slab_fast(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, r, marg, tnr, lbr);
+                if (exact_only) { sl = 2; sr = 2; lbl = lbr = -FLT_MAX; }
+                if (sl == 2) sl = slab_exact(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, d) ? 1 : 0;
+                if (sr == 2) sr = slab_exact(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, d) ? 1 : 0;
+                if (COUNT) { ++cnt_nodes; cnt_boxes += 2; }
+                const bool hl = sl != 0 && !(lbl > best.t);
+                const bool hr = sr != 0 && !(lbr > best.t);
+                const int left = __float_as_int(n3.x), right = __float_as_int(n3.y);
+                if (hl && hr) {
+                    int nearc = left, farc = right;
+                    if (tnr < tnl) { nearc = right; farc = left; }
+                    if (sp < LDS_STACK) lds_col[sp * TRACE_BLOCK] = farc; else ovf_col[(sp - LDS_STACK) * ovf_stride] = farc;
+                    ++sp;
+                    cur = nearc;
+                } else if (hl) cur = left;
+                else if (hr) cur = right;
+                else if (sp == 0) cur = CUR_DONE;
+                else { --sp; cur = (sp < LDS_STACK) ? lds_col[sp * TRACE_BLOCK] : ovf_col[(sp - LDS_STACK) * ovf_stride]; }
+            }
+        }
+
+        // ---------------- leaf phase ----------------
+        if (has_ray && cur < 0) {
             // ProcessIntersectionForLeafNode (BVHTree.cpp:177-190): fresh result, array order, accept t>0 && t < best-0.001
             const int leaf = ~cur;
             const DevLeaf lf = sc.leaves[leaf];
@@ -280,10 +341,15 @@ __device__ __forceinline__ void trace_closest(const DevScene &sc, f3 o, f3 d, fl
             // ProcessIntersectionForInternalNode (BVHTree.cpp:192-206) reduced over all leaves: smaller t wins, ties go
             // to the leaf that comes later in DFS order (Q4)
             if (local.prim >= 0 && (local.t < best.t || (local.t == best.t && leaf > best_leaf))) { best = local; best_leaf = leaf; }
+            if (sp == 0) cur = CUR_DONE;
+            else { --sp; cur = (sp < LDS_STACK) ? lds_col[sp * TRACE_BLOCK] : ovf_col[(sp - LDS_STACK) * ovf_stride]; }
         }
-        if (sp == 0) break;
-        --sp;
-        cur = (sp < LDS_STACK) ? lds_col[sp * TRACE_BLOCK] : ovf_col[(sp - LDS_STACK) * ovf_stride];
+
+        // ---------------- retire finished rays ----------------
+        if (has_ray && cur == CUR_DONE) {
+            io.store(sc, ray_idx, best);
+            has_ray = false;
+        }
     }
 }
 
@@ -350,61 +416,50 @@ __device__ __forceinline__ void flush_counters(DevCounters *counters, unsigned n
 // Raw closest-hit record written by k_trace and completed by k_shade_pre (finalize_hit needs acosf/atan2f/inverse code
 // that would otherwise set the register allocation of the traversal kernel):
 //   hit0 = (t, prim record | -1, beta, gamma)   hit1 = (ip.xyz, unused)
-template <bool COUNT, bool MOTION>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace(DevScene sc, LevelBuf lv, int n, int *ovf, int ovf_stride, DevCounters *counters) {
-    __shared__ int s_stack[LDS_STACK * TRACE_BLOCK];
-    const int gtid = blockIdx.x * TRACE_BLOCK + threadIdx.x;
-    const int nthreads = gridDim.x * TRACE_BLOCK;
-    unsigned cn = 0, cb = 0, ct = 0, cs = 0;
-    for (int i = gtid; i < n; i += nthreads) {
+struct ClosestIO {
+    LevelBuf lv;
+    __device__ __forceinline__ bool load(int i, f3 &o, f3 &d, float &time) const {
         const float4 ro = lv.ray_o[i], rd = lv.ray_d[i];
-        const f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
-        Cand best; int leaf;
-        trace_closest<COUNT, MOTION>(sc, o, d, ro.w, s_stack + threadIdx.x, ovf + gtid, ovf_stride, best, leaf, cn, cb, ct, cs);
+        o = mk3(ro.x, ro.y, ro.z); d = mk3(rd.x, rd.y, rd.z); time = ro.w;
+        return true;
+    }
+    __device__ __forceinline__ void store(const DevScene &, int i, const Cand &best) const {
         lv.hit0[i] = make_float4(best.t, __int_as_float(best.prim), best.beta, best.gamma);
         lv.hit1[i] = make_float4(best.ip.x, best.ip.y, best.ip.z, 0.0f);
     }
-    flush_counters<COUNT>(counters, cn, cb, ct, cs);
-}
-
+};
 // Shadow rays (Q7): a full closest-hit query, then the distance window test of
 // LightContributionCalculator::IsThereAnObjectBetweenLightAndIntersectionPoint (:130-145).
-template <bool COUNT, bool MOTION>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow(DevScene sc, ShadowBuf sb, int n, int *ovf, int ovf_stride, DevCounters *counters) {
-    __shared__ int s_stack[LDS_STACK * TRACE_BLOCK];
-    const int gtid = blockIdx.x * TRACE_BLOCK + threadIdx.x;
-    const int nthreads = gridDim.x * TRACE_BLOCK;
-    unsigned cn = 0, cb = 0, ct = 0, cs = 0;
-    for (int i = gtid; i < n; i += nthreads) {
+struct ShadowIO {
+    ShadowBuf sb;
+    __device__ __forceinline__ bool load(int i, f3 &o, f3 &d, float &time) const {
         const float4 ref = sb.ipref[i];
-        if (ref.w == 0.0f) { sb.occluded[i] = 0; continue; }
+        if (ref.w == 0.0f) { sb.occluded[i] = 0; return false; }
         const float4 ro = sb.o[i], rd = sb.d[i];
-        const f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
-        Cand best; int leaf;
-        trace_closest<COUNT, MOTION>(sc, o, d, ro.w, s_stack + threadIdx.x, ovf + gtid, ovf_stride, best, leaf, cn, cb, ct, cs);
+        o = mk3(ro.x, ro.y, ro.z); d = mk3(rd.x, rd.y, rd.z); time = ro.w;
+        return true;
+    }
+    __device__ __forceinline__ void store(const DevScene &sc, int i, const Cand &best) const {
         int occ = 0;
         if (best.prim >= 0) {
+            const float4 ref = sb.ipref[i];
             const float dist = norm3(best.ip - mk3(ref.x, ref.y, ref.z));
             const float se = sc.p.shadow_eps;
-            occ = (dist > se && dist < rd.w - se) ? 1 : 0;
+            occ = (dist > se && dist < sb.d[i].w - se) ? 1 : 0;
         }
         sb.occluded[i] = occ;
     }
-    flush_counters<COUNT>(counters, cn, cb, ct, cs);
-}
-
+};
 // rt_intersect_batch: AccelerationStructure::Intersect for n independent rays (traversal, then k_finalize_batch)
-template <bool COUNT, bool MOTION>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_batch(DevScene sc, const rt_ray *rays, rt_hit *hits, int n, int *ovf, int ovf_stride, DevCounters *counters) {
-    __shared__ int s_stack[LDS_STACK * TRACE_BLOCK];
-    const int gtid = blockIdx.x * TRACE_BLOCK + threadIdx.x;
-    const int nthreads = gridDim.x * TRACE_BLOCK;
-    unsigned cn = 0, cb = 0, ct = 0, cs = 0;
-    for (int i = gtid; i < n; i += nthreads) {
+struct BatchIO {
+    const rt_ray *rays;
+    rt_hit *hits;
+    __device__ __forceinline__ bool load(int i, f3 &o, f3 &d, float &time) const {
         const rt_ray r = rays[i];
-        const f3 o = ld3(r.origin), d = ld3(r.direction);
-        Cand best; int leaf;
-        trace_closest<COUNT, MOTION>(sc, o, d, r.time, s_stack + threadIdx.x, ovf + gtid, ovf_stride, best, leaf, cn, cb, ct, cs);
+        o = ld3(r.origin); d = ld3(r.direction); time = r.time;
+        return true;
+    }
+    __device__ __forceinline__ void store(const DevScene &, int i, const Cand &best) const {
         rt_hit out;                      // raw form: shape = prim record, uv = (beta, gamma); completed by k_finalize_batch
         out.t = best.t; out.shape = best.prim;
         out.ip[0] = best.ip.x; out.ip[1] = best.ip.y; out.ip[2] = best.ip.z;
@@ -412,6 +467,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_batch(DevScene sc, const 
         out.uv[0] = best.beta; out.uv[1] = best.gamma;
         hits[i] = out;
     }
+};
+
+template <bool COUNT, bool MOTION, class IO>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_generic(DevScene sc, IO io, int n, int *fetch_counter, int *ovf, int ovf_stride, DevCounters *counters) {
+    __shared__ int s_stack[LDS_STACK * TRACE_BLOCK];
+    const int gtid = blockIdx.x * TRACE_BLOCK + threadIdx.x;
+    unsigned cn = 0, cb = 0, ct = 0, cs = 0;
+    trace_persistent<COUNT, MOTION, IO>(sc, io, n, fetch_counter, s_stack + threadIdx.x, ovf + gtid, ovf_stride, cn, cb, ct, cs);
     flush_counters<COUNT>(counters, cn, cb, ct, cs);
 }
 __global__ __launch_bounds__(256) void k_finalize_batch(DevScene sc, const rt_ray *rays, rt_hit *hits, int n) {
@@ -436,30 +499,31 @@ static int trace_blocks(int n) {
     int cap = NUM_CUS * TRACE_BLOCKS_PER_CU;
     return want < cap ? (want < 1 ? 1 : want) : cap;
 }
-#define TRACE_DISPATCH(KERNEL, ...)                                                                                        \
-    do {                                                                                                                   \
-        const dim3 g(trace_blocks(n)), b(TRACE_BLOCK);                                                                     \
-        const bool cnt = counters != nullptr, mot = sc.p.has_motion != 0;                                                  \
-        if (cnt && mot) hipLaunchKernelGGL((KERNEL<true, true>), g, b, 0, s, __VA_ARGS__);                                 \
-        else if (cnt) hipLaunchKernelGGL((KERNEL<true, false>), g, b, 0, s, __VA_ARGS__);                                  \
-        else if (mot) hipLaunchKernelGGL((KERNEL<false, true>), g, b, 0, s, __VA_ARGS__);                                  \
-        else hipLaunchKernelGGL((KERNEL<false, false>), g, b, 0, s, __VA_ARGS__);                                          \
-    } while (0)
-
-void rt_launch_trace(hipStream_t s, const DevScene &sc, LevelBuf lv, int n, int *ovf, int ovf_depth, DevCounters *counters) {
-    (void)ovf_depth;
-    if (n <= 0) return;
-    TRACE_DISPATCH(k_trace, sc, lv, n, ovf, rt_trace_grid_threads(), counters);
+template <class IO>
+static void trace_dispatch(hipStream_t s, const DevScene &sc, IO io, int n, int *fetch_counter, int *ovf, DevCounters *counters) {
+    const dim3 g(trace_blocks(n)), b(TRACE_BLOCK);
+    const int stride = rt_trace_grid_threads();
+    const bool cnt = counters != nullptr, mot = sc.p.has_motion != 0;
+    if (cnt && mot) hipLaunchKernelGGL((k_trace_generic<true, true, IO>), g, b, 0, s, sc, io, n, fetch_counter, ovf, stride, counters);
+    else if (cnt) hipLaunchKernelGGL((k_trace_generic<true, false, IO>), g, b, 0, s, sc, io, n, fetch_counter, ovf, stride, counters);
+    else if (mot) hipLaunchKernelGGL((k_trace_generic<false, true, IO>), g, b, 0, s, sc, io, n, fetch_counter, ovf, stride, counters);
+    else hipLaunchKernelGGL((k_trace_generic<false, false, IO>), g, b, 0, s, sc, io, n, fetch_counter, ovf, stride, counters);
 }
-void rt_launch_trace_shadow(hipStream_t s, const DevScene &sc, ShadowBuf sb, int n, int *ovf, int ovf_depth, DevCounters *counters) {
-    (void)ovf_depth;
+// `fetch_counter` must point to a zeroed int that no other launch in flight uses.
+void rt_launch_trace(hipStream_t s, const DevScene &sc, LevelBuf lv, int n, int *fetch_counter, int *ovf, DevCounters *counters) {
     if (n <= 0) return;
-    TRACE_DISPATCH(k_trace_shadow, sc, sb, n, ovf, rt_trace_grid_threads(), counters);
+    ClosestIO io; io.lv = lv;
+    trace_dispatch(s, sc, io, n, fetch_counter, ovf, counters);
 }
-void rt_launch_trace_batch(hipStream_t s, const DevScene &sc, const rt_ray *rays, rt_hit *hits, int n, int *ovf, int ovf_depth, DevCounters *counters) {
-    (void)ovf_depth;
+void rt_launch_trace_shadow(hipStream_t s, const DevScene &sc, ShadowBuf sb, int n, int *fetch_counter, int *ovf, DevCounters *counters) {
     if (n <= 0) return;
-    TRACE_DISPATCH(k_trace_batch, sc, rays, hits, n, ovf, rt_trace_grid_threads(), counters);
+    ShadowIO io; io.sb = sb;
+    trace_dispatch(s, sc, io, n, fetch_counter, ovf, counters);
+}
+void rt_launch_trace_batch(hipStream_t s, const DevScene &sc, const rt_ray *rays, rt_hit *hits, int n, int *fetch_counter, int *ovf, DevCounters *counters) {
+    if (n <= 0) return;
+    BatchIO io; io.rays = rays; io.hits = hits;
+    trace_dispatch(s, sc, io, n, fetch_counter, ovf, counters);
     hipLaunchKernelGGL(k_finalize_batch, dim3((n + 255) / 256), dim3(256), 0, s, sc, rays, hits, n);
 }
 

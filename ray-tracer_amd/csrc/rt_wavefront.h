@@ -64,9 +64,10 @@ struct DevCounters {        // accumulated with atomics when counting is enabled
 };
 
 void rt_launch_raygen(hipStream_t s, const DevCamera &cam, const int *pixel_list, int first_pixel, int n_samples, LevelBuf lv);
-void rt_launch_trace(hipStream_t s, const DevScene &sc, LevelBuf lv, int n, int *overflow_stack, int overflow_depth, DevCounters *counters);
-void rt_launch_trace_shadow(hipStream_t s, const DevScene &sc, ShadowBuf sb, int n, int *overflow_stack, int overflow_depth, DevCounters *counters);
-void rt_launch_trace_batch(hipStream_t s, const DevScene &sc, const rt_ray *rays, rt_hit *hits, int n, int *overflow_stack, int overflow_depth, DevCounters *counters);
+// fetch_counter: a zeroed int in device memory, private to the launch (the persistent waves draw ray indices from it)
+void rt_launch_trace(hipStream_t s, const DevScene &sc, LevelBuf lv, int n, int *fetch_counter, int *overflow_stack, DevCounters *counters);
+void rt_launch_trace_shadow(hipStream_t s, const DevScene &sc, ShadowBuf sb, int n, int *fetch_counter, int *overflow_stack, DevCounters *counters);
+void rt_launch_trace_batch(hipStream_t s, const DevScene &sc, const rt_ray *rays, rt_hit *hits, int n, int *fetch_counter, int *overflow_stack, DevCounters *counters);
 void rt_launch_shade_pre(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, ShadowBuf sb);
 void rt_launch_shade_post(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, ShadowBuf sb, LevelBuf next, int depth, int *next_count, unsigned long long *ray_kind_counts);
 void rt_launch_backward(hipStream_t s, LevelBuf lv, int n, LevelBuf next, int has_next);

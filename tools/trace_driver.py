@@ -1,0 +1,18 @@
+"""Small GPU driver for profiling: uploads the config-2 scene and renders a few frames (no torch, no CPU baseline)."""
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+rt = importlib.import_module("ray-tracer_amd")
+synth = importlib.import_module("ray-tracer_amd.synth")
+
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+tris = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+soup = synth.dragon_standin_scene(tris, 800, 480)
+ctx = rt.Context(0)
+ctx.upload(soup)
+for _ in range(frames):
+    hdr, _, _, st = ctx.render(0, want_ids=False, timing=1)
+print("rays", list(st.rays), "ms_kernels %.3f ms_trace %.3f" % (st.ms_kernels, st.ms_trace))
