@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 3u
+#define RT_ABI_VERSION 4u
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -177,7 +177,7 @@ typedef struct rt_render_opts {
     int32_t compact_output;   /* 1: outputs hold only owned pixels, in rt_tile_pixel_order() order      */
     int32_t max_batch_samples;/* samples traced per wavefront batch; <=0 selects the default (4M)      */
     int32_t timing;           /* 1: bracket kernels with HIP events and fill rt_stats ms fields        */
-    int32_t _pad;
+    int32_t num_streams;      /* sub-batches in flight on separate HIP streams; <=0 selects the default (1), max 8 */
 } rt_render_opts;
 
 enum { RT_RAY_PRIMARY = 0, RT_RAY_SHADOW = 1, RT_RAY_REFLECT = 2, RT_RAY_REFRACT = 3, RT_RAY_KINDS = 4 };
@@ -190,9 +190,11 @@ typedef struct rt_stats {
     uint64_t sphere_tests;        /* sphere intersection tests                      */
     double ms_total;              /* wall time of the whole rt_render call          */
     double ms_kernels;            /* HIP-event time first kernel -> last kernel     */
-    double ms_trace;              /* summed HIP-event time of the trace kernels     */
+    double ms_trace;              /* summed HIP-event durations of the trace-kernel launches (launches on
+                                     different streams overlap, so this can exceed ms_kernels)                  */
     uint64_t trace_launches;      /* number of trace-kernel launches                */
     uint64_t trace_rays;          /* rays processed by those launches               */
+    double ms_trace_busy;         /* time during which at least one trace launch was running (union of intervals) */
 } rt_stats;
 
 typedef struct rt_ray {

@@ -3,8 +3,9 @@
 // Host orchestration of one frame (replaces DefaultRenderer::RenderCamera's 8 std::thread row bands,
 // reference src/DefaultRenderer.cpp:59-104): the owned pixels (interleaved tiles) are cut into batches of whole
 // pixels; per batch  raygen -> for level k: trace, shade_pre, trace_shadow, shade_post (children compacted into
-// level k+1) -> backward sweep -> resolve.  Everything is enqueued on one HIP stream; the only host round trip
-// per level is the 4-byte child count.
+// level k+1) -> backward sweep -> resolve.  Up to rt_render_opts.num_streams batches are in flight, each on its own
+// HIP stream with its own queues: a level's launch ends with a tail (the longest traversal chains, few lanes busy)
+// that the other streams' launches fill.  The only host round trip per level and stream is the 4-byte child count.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -82,6 +83,45 @@ struct LevelMem {
     }
 };
 
+// One in-flight batch: its own stream, queues, counters and traversal-stack overflow area.
+struct StreamLane {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_count = nullptr, ev_done = nullptr;
+    int *h_count = nullptr;                 // pinned: child count of the level just shaded
+    std::vector<LevelMem> levels;
+    struct ShadowMem {
+        DevArray<float4> o, d, ip, ldir;
+        DevArray<int> occ;
+        hipError_t ensure(size_t n) {
+            hipError_t e;
+            if ((e = o.ensure(n)) != hipSuccess) return e;
+            if ((e = d.ensure(n)) != hipSuccess) return e;
+            if ((e = ip.ensure(n)) != hipSuccess) return e;
+            if ((e = ldir.ensure(n)) != hipSuccess) return e;
+            return occ.ensure(n);
+        }
+        void release() { o.release(); d.release(); ip.release(); ldir.release(); occ.release(); }
+    } sh[2];                                // shadow rays of level k live in sh[k & 1] until level k+1's launch has traced them
+    DevArray<int> d_counts;                 // [child counts | fetch counters | - | shadow queue lengths] x (max_depth+2)
+    DevArray<int> d_overflow;
+    // state of the batch in flight
+    bool busy = false;
+    int64_t p0 = 0;
+    int np = 0, k = 0;
+    void release() {
+        for (auto &l : levels) l.release();
+        levels.clear();
+        sh[0].release(); sh[1].release(); d_counts.release(); d_overflow.release();
+        if (h_count) hipHostFree(h_count);
+        if (ev_count) hipEventDestroy(ev_count);
+        if (ev_done) hipEventDestroy(ev_done);
+        if (stream) hipStreamDestroy(stream);
+        h_count = nullptr; ev_count = ev_done = nullptr; stream = nullptr;
+    }
+};
+
+enum { RT_DEFAULT_STREAMS = 1, RT_MAX_STREAMS = 8 };
+
 }  // namespace
 
 struct rt_ctx {
@@ -103,12 +143,11 @@ struct rt_ctx {
     DevArray<rt_texture> d_textures;
     DevArray<uint8_t> d_texels;
     // wavefront state
-    std::vector<LevelMem> levels;
-    DevArray<float4> sh_o, sh_d, sh_ip;
-    DevArray<int> sh_occ;
+    std::vector<StreamLane> lanes;
+    hipEvent_t ev_ready = nullptr;
     DevArray<int> d_pixels;
-    DevArray<int> d_overflow;
-    DevArray<int> d_counts;                 // per-level child counters
+    DevArray<int> d_overflow;               // rt_intersect_batch
+    DevArray<int> d_counts;                 // rt_intersect_batch fetch counter
     DevArray<unsigned long long> d_kind;    // rays per kind
     DevArray<DevCounters> d_counters;
     DevArray<float> d_hdr;
@@ -122,8 +161,10 @@ struct rt_ctx {
 static void release_all(rt_ctx *c) {
     c->d_nodes.release(); c->d_leaves.release(); c->d_prims.release(); c->d_objects.release(); c->d_verts.release(); c->d_tri_vert.release();
     c->d_materials.release(); c->d_lights.release(); c->d_textures.release(); c->d_texels.release();
-    for (auto &l : c->levels) l.release();
-    c->sh_o.release(); c->sh_d.release(); c->sh_ip.release(); c->sh_occ.release(); c->d_pixels.release(); c->d_overflow.release();
+    for (auto &l : c->lanes) l.release();
+    c->lanes.clear();
+    if (c->ev_ready) { hipEventDestroy(c->ev_ready); c->ev_ready = nullptr; }
+    c->d_pixels.release(); c->d_overflow.release();
     c->d_counts.release(); c->d_kind.release(); c->d_counters.release(); c->d_hdr.release(); c->d_pid.release(); c->d_pt.release();
     c->d_rays.release(); c->d_hits.release();
 }
@@ -324,8 +365,33 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
         if (d_pt) HIP_TRY(c, hipMemsetAsync(d_pt, 0, n_out * sizeof(float), s));
     }
 
-    if ((int)c->levels.size() < max_depth + 2) c->levels.resize(max_depth + 2);
-    HIP_TRY(c, c->d_counts.ensure(3 * ((size_t)max_depth + 2)));
+    // streams
+    int n_streams = opts->num_streams > 0 ? std::min<int>(opts->num_streams, RT_MAX_STREAMS) : RT_DEFAULT_STREAMS;
+    int64_t batch_samples = opts->max_batch_samples > 0 ? opts->max_batch_samples : (4 << 20);
+    int64_t batch_pixels = std::max<int64_t>(1, batch_samples / spp);
+    if (batch_pixels * spp > 0x3fffffff) batch_pixels = 0x3fffffff / spp;
+    {   // split the frame evenly over the streams (whole 256-pixel runs), never above the caller's batch limit
+        int64_t share = (n_owned + n_streams - 1) / n_streams;
+        share = (share + 255) / 256 * 256;
+        batch_pixels = std::max<int64_t>(1, std::min(batch_pixels, share));
+    }
+    n_streams = (int)std::max<int64_t>(1, std::min<int64_t>(n_streams, (n_owned + batch_pixels - 1) / batch_pixels));
+    if ((int)c->lanes.size() < n_streams) c->lanes.resize(n_streams);
+    if (!c->ev_ready) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+    const size_t n_cnt = 4 * ((size_t)max_depth + 2);
+    for (int j = 0; j < n_streams; ++j) {
+        StreamLane &ln = c->lanes[j];
+        if (!ln.stream) {
+            HIP_TRY(c, hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+            HIP_TRY(c, hipEventCreateWithFlags(&ln.ev_count, hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&ln.ev_done, hipEventDisableTiming));
+            HIP_TRY(c, hipHostMalloc((void **)&ln.h_count, sizeof(int), hipHostMallocDefault));
+        }
+        if ((int)ln.levels.size() < max_depth + 2) ln.levels.resize(max_depth + 2);
+        HIP_TRY(c, ln.d_counts.ensure(n_cnt));
+        HIP_TRY(c, ln.d_overflow.ensure((size_t)std::max(1, c->overflow_depth) * rt_trace_grid_threads()));
+        ln.busy = false;
+    }
     HIP_TRY(c, c->d_kind.ensure(RT_RAY_KINDS));
     HIP_TRY(c, hipMemsetAsync(c->d_kind.p, 0, RT_RAY_KINDS * sizeof(unsigned long long), s));
     DevCounters *d_counters = nullptr;
@@ -335,74 +401,126 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
         d_counters = c->d_counters.p;
     }
 
-    int64_t batch_samples = opts->max_batch_samples > 0 ? opts->max_batch_samples : (4 << 20);
-    int64_t batch_pixels = std::max<int64_t>(1, batch_samples / spp);
-    if (batch_pixels * spp > 0x3fffffff) batch_pixels = 0x3fffffff / spp;
-
     hipEvent_t ev_first = nullptr, ev_last = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;
     const bool timing = stats && opts->timing;
     if (timing) { HIP_TRY(c, hipEventCreate(&ev_first)); HIP_TRY(c, hipEventCreate(&ev_last)); HIP_TRY(c, hipEventRecord(ev_first, s)); }
     uint64_t primary_rays = 0, trace_launches = 0, trace_rays = 0;
+    // the batch streams start after the uploads / clears queued on the context stream
+    HIP_TRY(c, hipEventRecord(c->ev_ready, s));
+    for (int j = 0; j < n_streams; ++j) HIP_TRY(c, hipStreamWaitEvent(c->lanes[j].stream, c->ev_ready, 0));
 
-    auto timed_trace = [&](auto launch) -> int {
+    auto timed_trace = [&](hipStream_t st, auto launch) -> int {
         if (timing) {
             hipEvent_t a, b;
             HIP_TRY(c, hipEventCreate(&a)); HIP_TRY(c, hipEventCreate(&b));
-            HIP_TRY(c, hipEventRecord(a, s));
+            HIP_TRY(c, hipEventRecord(a, st));
             launch();
-            HIP_TRY(c, hipEventRecord(b, s));
+            HIP_TRY(c, hipEventRecord(b, st));
             trace_events.push_back({a, b});
         } else launch();
         return RT_OK;
     };
 
-    for (int64_t p0 = 0; p0 < n_owned; p0 += batch_pixels) {
-        const int np = (int)std::min<int64_t>(batch_pixels, n_owned - p0);
-        const int n0 = np * spp;
-        primary_rays += (uint64_t)n0;
-        HIP_TRY(c, c->levels[0].ensure((size_t)n0));
-        c->levels[0].count = n0;
-        rt_launch_raygen(s, dc, c->d_pixels.p, (int)p0, n0, c->levels[0].view());
-        HIP_TRY(c, hipMemsetAsync(c->d_counts.p, 0, 3 * ((size_t)max_depth + 2) * sizeof(int), s));
-        int *fetch_closest = c->d_counts.p + (max_depth + 2), *fetch_shadow = c->d_counts.p + 2 * (max_depth + 2);
-        int last = 0;
-        for (int k = 0; k <= max_depth; ++k) {
-            LevelMem &lm = c->levels[k];
-            const int n = lm.count;
-            if (n == 0) break;
-            last = k;
-            int rc = timed_trace([&] { rt_launch_trace(s, c->dev, lm.view(), n, fetch_closest + k, c->d_overflow.p, d_counters); });
+    auto shadow_view = [&](StreamLane &ln, int k) -> ShadowBuf {
+        StreamLane::ShadowMem &m = ln.sh[k & 1];
+        ShadowBuf sb;
+        sb.o = m.o.p; sb.d = m.d.p; sb.ipref = m.ip.p; sb.ldir = m.ldir.p; sb.occluded = m.occ.p;
+        sb.count = ln.d_counts.p + 3 * (max_depth + 2) + k;
+        sb.capacity = (int)std::min<size_t>(m.o.cap, 0x7fffffff);
+        return sb;
+    };
+    auto shadow_bound = [&](StreamLane &ln, int k) -> int { return nl > 0 ? ln.levels[k].count * nl : 0; };
+    // After the last level: its shadow rays, its lighting, then the backward sweep and the resolve of the batch.
+    auto finish_batch = [&](StreamLane &ln, int last) -> int {
+        hipStream_t st = ln.stream;
+        const ShadowBuf sb = shadow_view(ln, last);
+        const int bound = shadow_bound(ln, last);
+        if (bound > 0) {
+            int rc = timed_trace(st, [&] { rt_launch_trace(st, c->dev, ln.levels[last].view(), 0, sb, bound, ln.d_counts.p + (max_depth + 2) + last + 1, ln.d_overflow.p, d_counters); });
             if (rc != RT_OK) return rc;
-            ++trace_launches; trace_rays += (uint64_t)n;
-            const size_t nsh = (size_t)n * (size_t)std::max(1, nl);
-            if (nsh > 0x7fffffff) { c->error = "shadow queue too large; lower max_batch_samples"; return RT_ERR_TOO_LARGE; }
-            HIP_TRY(c, c->sh_o.ensure(nsh)); HIP_TRY(c, c->sh_d.ensure(nsh)); HIP_TRY(c, c->sh_ip.ensure(nsh)); HIP_TRY(c, c->sh_occ.ensure(nsh));
-            ShadowBuf sb;
-            sb.o = c->sh_o.p; sb.d = c->sh_d.p; sb.ipref = c->sh_ip.p; sb.occluded = c->sh_occ.p; sb.capacity = (int)std::min<size_t>(c->sh_o.cap, 0x7fffffff);
-            rt_launch_shade_pre(s, c->dev, dc, lm.view(), n, sb);
-            if (nl > 0) {
-                rc = timed_trace([&] { rt_launch_trace_shadow(s, c->dev, sb, n * nl, fetch_shadow + k, c->d_overflow.p, d_counters); });
-                if (rc != RT_OK) return rc;
-                ++trace_launches; trace_rays += (uint64_t)n * nl;
-            }
-            LevelMem &nx = c->levels[k + 1];
-            nx.count = 0;
-            if (k < max_depth) {
-                if ((size_t)n * 2 > 0x3fffffff) { c->error = "ray queue too large; lower max_batch_samples"; return RT_ERR_TOO_LARGE; }
-                HIP_TRY(c, nx.ensure((size_t)n * 2));
-            }
-            rt_launch_shade_post(s, c->dev, dc, lm.view(), n, sb, nx.view(), k, c->d_counts.p + k + 1, c->d_kind.p);
-            if (k < max_depth) {
-                int child_count = 0;
-                HIP_TRY(c, hipMemcpyAsync(&child_count, c->d_counts.p + k + 1, sizeof(int), hipMemcpyDeviceToHost, s));
-                HIP_TRY(c, hipStreamSynchronize(s));
-                nx.count = child_count;
-            }
+            ++trace_launches; trace_rays += (uint64_t)bound;
         }
+        rt_launch_shade_post(st, c->dev, dc, ln.levels[last].view(), ln.levels[last].count, sb);
         for (int k = last; k >= 0; --k)
-            rt_launch_backward(s, c->levels[k].view(), c->levels[k].count, c->levels[k + 1].view(), (k < last) ? 1 : 0);
-        rt_launch_resolve(s, dc, c->d_pixels.p, (int)p0, np, c->levels[0].view(), compact ? 1 : 0, d_hdr, d_pid, d_pt);
+            rt_launch_backward(st, ln.levels[k].view(), ln.levels[k].count, ln.levels[k + 1].view(), (k < last) ? 1 : 0);
+        rt_launch_resolve(st, dc, c->d_pixels.p, (int)ln.p0, ln.np, ln.levels[0].view(), compact ? 1 : 0, d_hdr, d_pid, d_pt);
+        ln.busy = false;
+        return RT_OK;
+    };
+    // Level ln.k: ONE trace launch for its closest-hit rays and the shadow rays of level k-1, then the lighting of level
+    // k-1 and the surface pass of level k (shadow rays + children).  Leaves the lane waiting for the child count, or
+    // finishes the batch at the last level.
+    auto enqueue_level = [&](StreamLane &ln) -> int {
+        const int k = ln.k;
+        hipStream_t st = ln.stream;
+        LevelMem &lm = ln.levels[k];
+        const int n = lm.count;
+        int *counts = ln.d_counts.p;
+        const ShadowBuf sb_prev = shadow_view(ln, k > 0 ? k - 1 : 1);
+        const int bound_prev = k > 0 ? shadow_bound(ln, k - 1) : 0;
+        int rc = timed_trace(st, [&] { rt_launch_trace(st, c->dev, lm.view(), n, sb_prev, bound_prev, counts + (max_depth + 2) + k, ln.d_overflow.p, d_counters); });
+        if (rc != RT_OK) return rc;
+        ++trace_launches; trace_rays += (uint64_t)n + (uint64_t)bound_prev;
+        if (k > 0) rt_launch_shade_post(st, c->dev, dc, ln.levels[k - 1].view(), ln.levels[k - 1].count, sb_prev);
+        const size_t nsh = (size_t)n * (size_t)std::max(1, nl);
+        if (nsh > 0x3fffffff) { c->error = "shadow queue too large; lower max_batch_samples"; return RT_ERR_TOO_LARGE; }
+        HIP_TRY(c, ln.sh[k & 1].ensure(nsh));
+        LevelMem &nx = ln.levels[k + 1];
+        nx.count = 0;
+        if (k < max_depth) {
+            if ((size_t)n * 2 > 0x3fffffff) { c->error = "ray queue too large; lower max_batch_samples"; return RT_ERR_TOO_LARGE; }
+            HIP_TRY(c, nx.ensure((size_t)n * 2));
+        }
+        rt_launch_shade_pre(st, c->dev, dc, lm.view(), n, shadow_view(ln, k), nx.view(), k, counts + k + 1, c->d_kind.p);
+        if (k < max_depth) {
+            HIP_TRY(c, hipMemcpyAsync(ln.h_count, counts + k + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipEventRecord(ln.ev_count, st));
+            return RT_OK;                      // lane stays busy, waiting for the count
+        }
+        return finish_batch(ln, k);
+    };
+
+    int64_t next_p0 = 0;
+    for (;;) {
+        bool any = false;
+        for (int j = 0; j < n_streams; ++j) {
+            StreamLane &ln = c->lanes[j];
+            if (!ln.busy) {
+                if (next_p0 >= n_owned) continue;
+                // start the next batch on this stream
+                ln.p0 = next_p0;
+                ln.np = (int)std::min<int64_t>(batch_pixels, n_owned - next_p0);
+                next_p0 += ln.np;
+                const int n0 = ln.np * spp;
+                primary_rays += (uint64_t)n0;
+                HIP_TRY(c, ln.levels[0].ensure((size_t)n0));
+                ln.levels[0].count = n0;
+                rt_launch_raygen(ln.stream, dc, c->d_pixels.p, (int)ln.p0, n0, ln.levels[0].view());
+                HIP_TRY(c, hipMemsetAsync(ln.d_counts.p, 0, n_cnt * sizeof(int), ln.stream));
+                ln.k = 0;
+                ln.busy = true;
+                int rc = enqueue_level(ln);
+                if (rc != RT_OK) return rc;
+                any = true;
+                continue;
+            }
+            // the lane waits for the child count of level ln.k
+            any = true;
+            HIP_TRY(c, hipEventSynchronize(ln.ev_count));
+            const int child_count = *ln.h_count;
+            ln.levels[ln.k + 1].count = child_count;
+            int rc;
+            if (child_count == 0) rc = finish_batch(ln, ln.k);
+            else { ++ln.k; rc = enqueue_level(ln); }
+            if (rc != RT_OK) return rc;
+        }
+        if (!any) break;
+    }
+    // the context stream continues after every batch stream has drained
+    for (int j = 0; j < n_streams; ++j) {
+        HIP_TRY(c, hipEventRecord(c->lanes[j].ev_done, c->lanes[j].stream));
+        HIP_TRY(c, hipStreamWaitEvent(s, c->lanes[j].ev_done, 0));
     }
     if (timing) HIP_TRY(c, hipEventRecord(ev_last, s));
     if (!opts->output_on_device) {
@@ -427,14 +545,38 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
         stats->rays[RT_RAY_PRIMARY] = primary_rays;
         stats->rays[RT_RAY_SHADOW] = kinds[RT_RAY_SHADOW]; stats->rays[RT_RAY_REFLECT] = kinds[RT_RAY_REFLECT]; stats->rays[RT_RAY_REFRACT] = kinds[RT_RAY_REFRACT];
         stats->node_visits = hc.node_visits; stats->box_tests = hc.box_tests; stats->tri_tests = hc.tri_tests; stats->sphere_tests = hc.sphere_tests;
+        if (getenv("RT_TRACE_DEBUG")) {
+            for (int q = 0; q < 2; ++q) {
+                fprintf(stderr, "[rt] trace lanes %s:", q ? "shadow" : "closest");
+                for (int k = 0; k < 10; ++k) fprintf(stderr, " %llu", hc.dbg[q][k]);
+                fprintf(stderr, "\n[rt] steps histogram (log2 buckets):");
+                for (int k = 0; k < 16; ++k) fprintf(stderr, " %llu", hc.hist[q * 16 + k]);
+                fprintf(stderr, "\n");
+            }
+        }
         stats->trace_launches = trace_launches; stats->trace_rays = trace_rays;
         if (timing) {
             float ms = 0;
             hipEventElapsedTime(&ms, ev_first, ev_last);
             stats->ms_kernels = ms;
             double tr = 0;
-            for (auto &pr : trace_events) { float m = 0; hipEventElapsedTime(&m, pr.first, pr.second); tr += m; }
+            std::vector<std::pair<float, float>> iv;
+            for (auto &pr : trace_events) {
+                float m = 0, a = 0;
+                hipEventElapsedTime(&m, pr.first, pr.second);
+                hipEventElapsedTime(&a, ev_first, pr.first);
+                tr += m;
+                iv.push_back({a, a + m});
+            }
             stats->ms_trace = tr;
+            std::sort(iv.begin(), iv.end());
+            double busy = 0; float cur_a = 0, cur_b = -1;
+            for (auto &x : iv) {
+                if (cur_b < cur_a || x.first > cur_b) { if (cur_b >= cur_a) busy += cur_b - cur_a; cur_a = x.first; cur_b = x.second; }
+                else cur_b = std::max(cur_b, x.second);
+            }
+            if (cur_b >= cur_a) busy += cur_b - cur_a;
+            stats->ms_trace_busy = busy;
         }
         stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     }

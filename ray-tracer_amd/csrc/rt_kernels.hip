@@ -226,10 +226,12 @@ __device__ __forceinline__ int slab_fast(f3 bmin, f3 bmax, f3 o, f3 r, f3 marg, 
 // ----------------------------------------------------------------------------------------------------
 #define CUR_DONE 0x7ffffffe      // lane finished its ray (stack empty)
 #define NODE_PHASE_MIN_LANES 12  // leave the node phase when fewer lanes than this still sit on internal nodes
+#define TRACE_CHUNK 64           // rays a wave reserves per atomic
+#define REFILL_MIN_IDLE 8        // refill once this many lanes are idle
 
 template <bool COUNT, bool MOTION, class IO>
 __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io, int n, int *fetch_counter, int *lds_col, int *ovf_col,
-                                                 int ovf_stride, unsigned &cnt_nodes, unsigned &cnt_boxes, unsigned &cnt_tris, unsigned &cnt_sph) {
+                                                 int ovf_stride, unsigned &cnt_nodes, unsigned &cnt_boxes, unsigned &cnt_tris, unsigned &cnt_sph, unsigned *dbg, unsigned long long *hist) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const float4 *nodes4 = reinterpret_cast<const float4 *>(sc.nodes);
@@ -245,21 +247,33 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
     best.t = FLT_MAX; best.prim = -1; best.ip = mk3(0, 0, 0); best.beta = best.gamma = 0;
     ObjXf xf;
     xf.id = -2; xf.flags = 0; xf.o = o; xf.d = d;
-    bool exhausted = false;          // wave-uniform: the global queue has no more rays
+    unsigned ray_steps = 0;
+    bool exhausted = false;          // wave-uniform: the global queue has no more chunks
+    int chunk_next = 0, chunk_end = 0;
 
     for (;;) {
+        if (COUNT) { ++dbg[0]; if (has_ray) ++dbg[1]; }
         // ---------------- refill idle lanes ----------------
-        if (!exhausted) {
+        // The wave owns a chunk [chunk_next, chunk_end) of the queue (one atomic per TRACE_CHUNK rays) and hands its rays to
+        // idle lanes in lane order, once at least REFILL_MIN_IDLE lanes wait (fewer: the ray loads are not worth a pass).
+        {
             const unsigned long long idle = __ballot(!has_ray);
-            if (idle) {
-                const int want = __popcll(idle);
-                int base = 0;
-                if (lane == __ffsll((long long)idle) - 1) base = atomicAdd(fetch_counter, want);
-                base = __shfl(base, __ffsll((long long)idle) - 1);
-                if (base + want >= n) exhausted = true;
-                if (!has_ray) {
-                    const int mine = base + __popcll(idle & lt_mask);
-                    if (mine < n && io.load(mine, o, d, time)) {
+            const int nidle = __popcll(idle);
+            if (nidle >= REFILL_MIN_IDLE && (!exhausted || chunk_next < chunk_end)) {
+                if (chunk_next >= chunk_end) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(fetch_counter, TRACE_CHUNK);
+                    base = __shfl(base, 0);
+                    chunk_next = base;
+                    chunk_end = base + TRACE_CHUNK < n ? base + TRACE_CHUNK : n;
+                    if (base + TRACE_CHUNK >= n) exhausted = true;
+                }
+                const int avail = chunk_end > chunk_next ? chunk_end - chunk_next : 0;
+                const int rank = __popcll(idle & lt_mask);
+                if (COUNT) { ++dbg[2]; if (!has_ray && rank < avail) ++dbg[3]; }
+                if (!has_ray && rank < avail) {
+                    const int mine = chunk_next + rank;
+                    if (io.load(mine, o, d, time)) {
                         ray_idx = mine;
                         best.t = FLT_MAX; best.prim = -1; best.ip = mk3(0, 0, 0); best.beta = best.gamma = 0;
                         best_leaf = -1; sp = 0; xf.id = -2;
@@ -280,9 +294,10 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                         }
                     }
                 }
+                chunk_next += nidle < avail ? nidle : avail;
             }
         }
-        if (!__any(has_ray)) { if (exhausted) break; else continue; }
+        if (!__any(has_ray)) { if (exhausted && chunk_next >= chunk_end) break; else continue; }
 
         // ---------------- node phase ----------------
         for (;;) {
@@ -290,15 +305,17 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
             const unsigned long long m = __ballot(at_node);
             if (m == 0) break;
             if (__popcll(m) < NODE_PHASE_MIN_LANES && __any(has_ray && cur < 0)) break;   // enough leaf work is waiting
+            if (COUNT) { ++dbg[4]; if (at_node) ++dbg[5]; }
             if (at_node) {
                 const float4 n0 = nodes4[cur * 4 + 0], n1 = nodes4[cur * 4 + 1], n2 = nodes4[cur * 4 + 2], n3 = nodes4[cur * 4 + 3];
                 float tnl, tnr, lbl, lbr;
                 int sl = slab_fast(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, r, marg, tnl, lbl);
                 int sr = slab_fast(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, r, marg, tnr, lbr);
                 if (exact_only) { sl = 2; sr = 2; lbl = lbr = -FLT_MAX; }
+                if (COUNT) { if (sl == 2 || sr == 2) ++dbg[9]; if (__any(sl == 2 || sr == 2)) ++dbg[8]; }
                 if (sl == 2) sl = slab_exact(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, d) ? 1 : 0;
                 if (sr == 2) sr = slab_exact(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, d) ? 1 : 0;
-                if (COUNT) { ++cnt_nodes; cnt_boxes += 2; }
+                if (COUNT) { ++cnt_nodes; cnt_boxes += 2; ++ray_steps; }
                 const bool hl = sl != 0 && !(lbl > best.t);
                 const bool hr = sr != 0 && !(lbr > best.t);
                 const int left = __float_as_int(n3.x), right = __float_as_int(n3.y);
@@ -316,6 +333,12 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
         }
 
         // ---------------- leaf phase ----------------
+        if (COUNT) {
+            int mx = (has_ray && cur < 0) ? sc.leaves[~cur].count : 0;
+            dbg[7] += mx;
+            for (int off = 32; off > 0; off >>= 1) { int other = __shfl_xor(mx, off); mx = other > mx ? other : mx; }
+            dbg[6] += mx;
+        }
         if (has_ray && cur < 0) {
             // ProcessIntersectionForLeafNode (BVHTree.cpp:177-190): fresh result, array order, accept t>0 && t < best-0.001
             const int leaf = ~cur;
@@ -347,6 +370,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
 
         // ---------------- retire finished rays ----------------
         if (has_ray && cur == CUR_DONE) {
+            if (COUNT && hist) { atomicAdd(&hist[io.kind(ray_idx) * 16 + (ray_steps ? 32 - __clz(ray_steps) : 0)], 1ull); ray_steps = 0; }
             io.store(sc, ray_idx, best);
             has_ray = false;
         }
@@ -413,45 +437,46 @@ __device__ __forceinline__ void flush_counters(DevCounters *counters, unsigned n
     }
 }
 
-// Raw closest-hit record written by k_trace and completed by k_shade_pre (finalize_hit needs acosf/atan2f/inverse code
-// that would otherwise set the register allocation of the traversal kernel):
-//   hit0 = (t, prim record | -1, beta, gamma)   hit1 = (ip.xyz, unused)
-struct ClosestIO {
+// Ray source / result sink of the render launches.  One launch serves the closest-hit queue of a level (indices
+// [0, n_closest)) AND the compact shadow queue of the level before it (the indices after that); either part may be empty.
+//   closest: raw record hit0 = (t, prim record | -1, beta, gamma), hit1 = (ip.xyz, unused), completed by k_shade_pre
+//            (finalize_hit needs acosf/atan2f/inverse code that would otherwise set the register allocation here)
+//   shadow (Q7): a full closest-hit query, then the distance window test of
+//            LightContributionCalculator::IsThereAnObjectBetweenLightAndIntersectionPoint (:130-145)
+struct RenderIO {
+    enum { DBG_SET = 0 };
     LevelBuf lv;
-    __device__ __forceinline__ bool load(int i, f3 &o, f3 &d, float &time) const {
-        const float4 ro = lv.ray_o[i], rd = lv.ray_d[i];
-        o = mk3(ro.x, ro.y, ro.z); d = mk3(rd.x, rd.y, rd.z); time = ro.w;
-        return true;
-    }
-    __device__ __forceinline__ void store(const DevScene &, int i, const Cand &best) const {
-        lv.hit0[i] = make_float4(best.t, __int_as_float(best.prim), best.beta, best.gamma);
-        lv.hit1[i] = make_float4(best.ip.x, best.ip.y, best.ip.z, 0.0f);
-    }
-};
-// Shadow rays (Q7): a full closest-hit query, then the distance window test of
-// LightContributionCalculator::IsThereAnObjectBetweenLightAndIntersectionPoint (:130-145).
-struct ShadowIO {
+    int n_closest;
     ShadowBuf sb;
+    __device__ __forceinline__ int kind(int i) const { return i < n_closest ? 0 : 1; }
     __device__ __forceinline__ bool load(int i, f3 &o, f3 &d, float &time) const {
-        const float4 ref = sb.ipref[i];
-        if (ref.w == 0.0f) { sb.occluded[i] = 0; return false; }
-        const float4 ro = sb.o[i], rd = sb.d[i];
+        const float4 *po = lv.ray_o, *pd = lv.ray_d;
+        if (i >= n_closest) { i -= n_closest; po = sb.o; pd = sb.d; }
+        const float4 ro = po[i], rd = pd[i];
         o = mk3(ro.x, ro.y, ro.z); d = mk3(rd.x, rd.y, rd.z); time = ro.w;
         return true;
     }
     __device__ __forceinline__ void store(const DevScene &sc, int i, const Cand &best) const {
+        if (i < n_closest) {
+            lv.hit0[i] = make_float4(best.t, __int_as_float(best.prim), best.beta, best.gamma);
+            lv.hit1[i] = make_float4(best.ip.x, best.ip.y, best.ip.z, 0.0f);
+            return;
+        }
+        i -= n_closest;
+        const float4 ref = sb.ipref[i];             // shaded point, result slot
         int occ = 0;
         if (best.prim >= 0) {
-            const float4 ref = sb.ipref[i];
             const float dist = norm3(best.ip - mk3(ref.x, ref.y, ref.z));
             const float se = sc.p.shadow_eps;
             occ = (dist > se && dist < sb.d[i].w - se) ? 1 : 0;
         }
-        sb.occluded[i] = occ;
+        sb.occluded[__float_as_int(ref.w)] = occ;
     }
 };
 // rt_intersect_batch: AccelerationStructure::Intersect for n independent rays (traversal, then k_finalize_batch)
 struct BatchIO {
+    enum { DBG_SET = 0 };
+    __device__ __forceinline__ int kind(int) const { return 0; }
     const rt_ray *rays;
     rt_hit *hits;
     __device__ __forceinline__ bool load(int i, f3 &o, f3 &d, float &time) const {
@@ -470,12 +495,21 @@ struct BatchIO {
 };
 
 template <bool COUNT, bool MOTION, class IO>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_generic(DevScene sc, IO io, int n, int *fetch_counter, int *ovf, int ovf_stride, DevCounters *counters) {
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_generic(DevScene sc, IO io, int n, const int *n_dev, int *fetch_counter, int *ovf, int ovf_stride, DevCounters *counters) {
     __shared__ int s_stack[LDS_STACK * TRACE_BLOCK];
+    if (n_dev) n += *n_dev;                       // + the part of the queue whose length was produced on the device
     const int gtid = blockIdx.x * TRACE_BLOCK + threadIdx.x;
     unsigned cn = 0, cb = 0, ct = 0, cs = 0;
-    trace_persistent<COUNT, MOTION, IO>(sc, io, n, fetch_counter, s_stack + threadIdx.x, ovf + gtid, ovf_stride, cn, cb, ct, cs);
+    unsigned dbg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    trace_persistent<COUNT, MOTION, IO>(sc, io, n, fetch_counter, s_stack + threadIdx.x, ovf + gtid, ovf_stride, cn, cb, ct, cs, dbg, counters ? &counters->hist[0] : nullptr);
     flush_counters<COUNT>(counters, cn, cb, ct, cs);
+    if (COUNT && counters) {
+        for (int k = 0; k < 10; ++k) {
+            unsigned v = dbg[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&counters->dbg[IO::DBG_SET][k], (unsigned long long)v);
+        }
+    }
 }
 __global__ __launch_bounds__(256) void k_finalize_batch(DevScene sc, const rt_ray *rays, rt_hit *hits, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -500,30 +534,34 @@ static int trace_blocks(int n) {
     return want < cap ? (want < 1 ? 1 : want) : cap;
 }
 template <class IO>
-static void trace_dispatch(hipStream_t s, const DevScene &sc, IO io, int n, int *fetch_counter, int *ovf, DevCounters *counters) {
+static void trace_dispatch(hipStream_t s, const DevScene &sc, IO io, int n, const int *n_dev, int *fetch_counter, int *ovf, DevCounters *counters) {
     const dim3 g(trace_blocks(n)), b(TRACE_BLOCK);
     const int stride = rt_trace_grid_threads();
     const bool cnt = counters != nullptr, mot = sc.p.has_motion != 0;
-    if (cnt && mot) hipLaunchKernelGGL((k_trace_generic<true, true, IO>), g, b, 0, s, sc, io, n, fetch_counter, ovf, stride, counters);
-    else if (cnt) hipLaunchKernelGGL((k_trace_generic<true, false, IO>), g, b, 0, s, sc, io, n, fetch_counter, ovf, stride, counters);
-    else if (mot) hipLaunchKernelGGL((k_trace_generic<false, true, IO>), g, b, 0, s, sc, io, n, fetch_counter, ovf, stride, counters);
-    else hipLaunchKernelGGL((k_trace_generic<false, false, IO>), g, b, 0, s, sc, io, n, fetch_counter, ovf, stride, counters);
+    if (cnt && mot) hipLaunchKernelGGL((k_trace_generic<true, true, IO>), g, b, 0, s, sc, io, n, n_dev, fetch_counter, ovf, stride, counters);
+    else if (cnt) hipLaunchKernelGGL((k_trace_generic<true, false, IO>), g, b, 0, s, sc, io, n, n_dev, fetch_counter, ovf, stride, counters);
+    else if (mot) hipLaunchKernelGGL((k_trace_generic<false, true, IO>), g, b, 0, s, sc, io, n, n_dev, fetch_counter, ovf, stride, counters);
+    else hipLaunchKernelGGL((k_trace_generic<false, false, IO>), g, b, 0, s, sc, io, n, n_dev, fetch_counter, ovf, stride, counters);
 }
-// `fetch_counter` must point to a zeroed int that no other launch in flight uses.
-void rt_launch_trace(hipStream_t s, const DevScene &sc, LevelBuf lv, int n, int *fetch_counter, int *ovf, DevCounters *counters) {
-    if (n <= 0) return;
-    ClosestIO io; io.lv = lv;
-    trace_dispatch(s, sc, io, n, fetch_counter, ovf, counters);
-}
-void rt_launch_trace_shadow(hipStream_t s, const DevScene &sc, ShadowBuf sb, int n, int *fetch_counter, int *ovf, DevCounters *counters) {
-    if (n <= 0) return;
-    ShadowIO io; io.sb = sb;
-    trace_dispatch(s, sc, io, n, fetch_counter, ovf, counters);
+// `fetch_counter` must point to a zeroed int that no other launch in flight uses.  n_closest rays of lv (may be 0) and the
+// shadow queue sb (its length is read on the device; `shadow_bound` >= that length sizes the launch; 0 = no shadow part).
+void rt_launch_trace(hipStream_t s, const DevScene &sc, LevelBuf lv, int n_closest, ShadowBuf sb, int shadow_bound, int *fetch_counter, int *ovf,
+                     DevCounters *counters) {
+    if (n_closest <= 0 && shadow_bound <= 0) return;
+    RenderIO io; io.lv = lv; io.n_closest = n_closest > 0 ? n_closest : 0; io.sb = sb;
+    const dim3 g(trace_blocks(io.n_closest + (shadow_bound > 0 ? shadow_bound : 0))), b(TRACE_BLOCK);
+    const int stride = rt_trace_grid_threads();
+    const int *n_dev = shadow_bound > 0 ? sb.count : nullptr;
+    const bool cnt = counters != nullptr, mot = sc.p.has_motion != 0;
+    if (cnt && mot) hipLaunchKernelGGL((k_trace_generic<true, true, RenderIO>), g, b, 0, s, sc, io, io.n_closest, n_dev, fetch_counter, ovf, stride, counters);
+    else if (cnt) hipLaunchKernelGGL((k_trace_generic<true, false, RenderIO>), g, b, 0, s, sc, io, io.n_closest, n_dev, fetch_counter, ovf, stride, counters);
+    else if (mot) hipLaunchKernelGGL((k_trace_generic<false, true, RenderIO>), g, b, 0, s, sc, io, io.n_closest, n_dev, fetch_counter, ovf, stride, counters);
+    else hipLaunchKernelGGL((k_trace_generic<false, false, RenderIO>), g, b, 0, s, sc, io, io.n_closest, n_dev, fetch_counter, ovf, stride, counters);
 }
 void rt_launch_trace_batch(hipStream_t s, const DevScene &sc, const rt_ray *rays, rt_hit *hits, int n, int *fetch_counter, int *ovf, DevCounters *counters) {
     if (n <= 0) return;
     BatchIO io; io.rays = rays; io.hits = hits;
-    trace_dispatch(s, sc, io, n, fetch_counter, ovf, counters);
+    trace_dispatch(s, sc, io, n, nullptr, fetch_counter, ovf, counters);
     hipLaunchKernelGGL(k_finalize_batch, dim3((n + 255) / 256), dim3(256), 0, s, sc, rays, hits, n);
 }
 
@@ -842,58 +880,6 @@ __device__ __forceinline__ bool replaces_all(const DevScene &sc, const DevObject
     return ob.tex_color >= 0 && sc.textures[ob.tex_color].decal == RT_DECAL_REPLACE_ALL;
 }
 
-// Per hit: texture-tweaked normal (written back into the hit record) and one shadow ray per light.
-__global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, LevelBuf lv, int n, ShadowBuf sb) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int nl = sc.p.n_lights;
-    const int4 meta = lv.ray_m[i];
-    const float4 ray_o = lv.ray_o[i], ray_d = lv.ray_d[i];
-    Surf s;
-    {   // complete the raw record k_trace left (what Triangle::Intersect / Sphere::Intersect return for the winner)
-        const float4 r0 = lv.hit0[i], r1 = lv.hit1[i];
-        Cand best;
-        best.t = r0.x; best.prim = __float_as_int(r0.y); best.beta = r0.z; best.gamma = r0.w; best.ip = mk3(r1.x, r1.y, r1.z);
-        HitOut h;
-        finalize_hit(sc, mk3(ray_o.x, ray_o.y, ray_o.z), mk3(ray_d.x, ray_d.y, ray_d.z), ray_o.w, best, h);
-        lv.hit0[i] = make_float4(h.t, __int_as_float(h.shape), __int_as_float(h.object), __int_as_float(h.prim));
-        lv.hit1[i] = make_float4(h.ip.x, h.ip.y, h.ip.z, h.n.x);
-        lv.hit2[i] = make_float4(h.n.y, h.n.z, h.u, h.v);
-        lv.hit3[i] = make_float4(h.theta, h.phi, 0.0f, 0.0f);
-        s.ip = h.ip; s.n = h.n; s.u = h.u; s.v = h.v; s.theta = h.theta; s.phi = h.phi; s.shape = h.shape; s.object = h.object; s.prim = h.prim;
-    }
-    bool lit = s.object >= 0;
-    if (lit) {
-        const DevObject &ob = sc.objects[s.object];
-        if (replaces_all(sc, ob)) lit = false;                         // LightContributionCalculator.cpp:54-55
-        else {
-            if (ob.tex_normal >= 0) {
-                s.n = tweak_normal(sc, s, ob.tex_normal);
-                lv.hit1[i].w = s.n.x;
-                float4 h2 = lv.hit2[i];
-                h2.x = s.n.y; h2.y = s.n.z;
-                lv.hit2[i] = h2;
-            }
-            if (meta.w >= 0 && meta.w == s.object) lit = false;        // IsInternalReflection (Q26)
-        }
-    }
-    const float time = ray_o.w;
-    for (int l = 0; l < nl; ++l) {
-        const int k = i * nl + l;
-        if (!lit) { sb.ipref[k] = make_float4(0, 0, 0, 0); continue; }
-        f3 to_light; float dist;
-        light_vars(sc.lights[l], l, s.ip, cam.seed, meta, to_light, dist);
-        const f3 so = s.ip + s.n * sc.p.shadow_eps;                    // LightContributionCalculator.cpp:133
-        sb.o[k] = make_float4(so.x, so.y, so.z, time);
-        sb.d[k] = make_float4(to_light.x, to_light.y, to_light.z, dist);
-        sb.ipref[k] = make_float4(s.ip.x, s.ip.y, s.ip.z, 1.0f);
-    }
-}
-void rt_launch_shade_pre(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, ShadowBuf sb) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_shade_pre, dim3((n + 255) / 256), dim3(256), 0, s, sc, cam, lv, n, sb);
-}
-
 // wave64 compaction: every lane asks for `want` (0..2) slots; one atomic per wave reserves the total; returns the
 // first slot of this lane.  __ballot is 64 bits wide on gfx950.
 __device__ __forceinline__ int wave_alloc(int want, int *counter) {
@@ -903,177 +889,236 @@ __device__ __forceinline__ int wave_alloc(int want, int *counter) {
     const int prefix = __popcll(m1 & below) + __popcll(m2 & below);
     const int total = __popcll(m1) + __popcll(m2);
     int base = 0;
-    if (lane == 0 && total > 0) base = atomicAdd(counter, total);
-    base = __shfl(base, 0);
+    const int leader = __ffsll((long long)__ballot(true)) - 1;      // first lane still executing (lanes >= n have returned)
+    if (lane == leader && total > 0) base = atomicAdd(counter, total);
+    base = __shfl(base, leader);
     return base + prefix;
 }
 
-__global__ __launch_bounds__(256) void k_shade_post(DevScene sc, DevCamera cam, LevelBuf lv, int n, ShadowBuf sb, LevelBuf next, int depth,
-                                                    int *next_count, unsigned long long *kind_counts) {
+// Per hit, right after the closest-hit trace of level `depth`: complete the hit record, apply the normal texture, emit one
+// shadow ray per light into the compact shadow queue, and spawn the reflection / refraction children into level depth+1
+// (RecursiveComputation.cpp) together with the coefficients the backward sweep folds them with.  Nothing here needs the
+// shadow results, so the children of this level and the shadow rays of this level are traced by ONE launch.
+__global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, LevelBuf lv, int n, ShadowBuf sb, LevelBuf next, int depth,
+                                                   int *next_count, unsigned long long *kind_counts) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = i < n;
-    int want = 0;
-    // values carried from the "decide" half to the "emit" half
-    f3 L = mk3(0, 0, 0), mrc = mk3(0, 0, 0), absorb = mk3(1, 1, 1);
+    if (i >= n) return;
+    const int nl = sc.p.n_lights;
+    const int4 meta = lv.ray_m[i];
+    const float4 ray_o = lv.ray_o[i], ray_d = lv.ray_d[i];
+    const f3 o = mk3(ray_o.x, ray_o.y, ray_o.z), d = mk3(ray_d.x, ray_d.y, ray_d.z);
+    const float time = ray_o.w;
+    Surf s;
+    {   // complete the raw record k_trace left (what Triangle::Intersect / Sphere::Intersect return for the winner)
+        const float4 r0 = lv.hit0[i], r1 = lv.hit1[i];
+        Cand best;
+        best.t = r0.x; best.prim = __float_as_int(r0.y); best.beta = r0.z; best.gamma = r0.w; best.ip = mk3(r1.x, r1.y, r1.z);
+        HitOut h;
+        finalize_hit(sc, o, d, time, best, h);
+        s.ip = h.ip; s.n = h.n; s.u = h.u; s.v = h.v; s.theta = h.theta; s.phi = h.phi; s.shape = h.shape; s.object = h.object; s.prim = h.prim;
+        lv.hit0[i] = make_float4(h.t, __int_as_float(h.shape), __int_as_float(h.object), __int_as_float(h.prim));
+        lv.hit3[i] = make_float4(h.theta, h.phi, 0.0f, 0.0f);
+    }
+    bool lit = s.object >= 0, recurse = false;
+    const bool internal = s.object >= 0 && meta.w >= 0 && meta.w == s.object;      // IsInternalReflection (Q26)
+    int mat_index = 0;
+    if (lit) {
+        const DevObject &ob = sc.objects[s.object];
+        mat_index = ob.material;
+        if (replaces_all(sc, ob)) lit = false;                         // LightContributionCalculator.cpp:54-55
+        else {
+            if (ob.tex_normal >= 0) s.n = tweak_normal(sc, s, ob.tex_normal);
+            recurse = true;
+            if (internal) lit = false;
+        }
+    }
+    lv.hit1[i] = make_float4(s.ip.x, s.ip.y, s.ip.z, s.n.x);
+    lv.hit2[i] = make_float4(s.n.y, s.n.z, s.u, s.v);
+
+    // ---- shadow rays: COMPACT queue (one wave-wide reservation per light: a wave's rays towards one light sit together,
+    // which is also the coherent order); the result is written to the ray's slot (hit i, light l) by the trace kernel.
+    for (int l = 0; l < nl; ++l) {
+        const int k = i * nl + l;
+        const int q = wave_alloc(lit ? 1 : 0, sb.count);
+        if (!lit) { sb.occluded[k] = 0; continue; }
+        f3 to_light; float dist;
+        light_vars(sc.lights[l], l, s.ip, cam.seed, meta, to_light, dist);
+        const f3 so = s.ip + s.n * sc.p.shadow_eps;                    // LightContributionCalculator.cpp:133
+        sb.ldir[k] = make_float4(to_light.x, to_light.y, to_light.z, dist);
+        sb.o[q] = make_float4(so.x, so.y, so.z, time);
+        sb.d[q] = make_float4(to_light.x, to_light.y, to_light.z, dist);
+        sb.ipref[q] = make_float4(s.ip.x, s.ip.y, s.ip.z, __int_as_float(k));
+    }
+
+    // ---- children (RecursiveComputation.cpp:25-30) ----
+    f3 mrc = mk3(0, 0, 0), absorb = mk3(1, 1, 1);
     float refl_coef = 0, refr_coef = 0;
-    int flags = 0;
+    int flags = s.object >= 0 ? NODE_HIT : 0;
     bool has_refr = false, has_refl = false;
-    f3 refl_o, refl_d, refr_o, refr_d;
-    float refl_n = 1, refr_n = 1, time = 0;
+    f3 refl_o = mk3(0, 0, 0), refl_d = mk3(0, 0, 0), refr_o = mk3(0, 0, 0), refr_d = mk3(0, 0, 0);
+    float refl_n = 1, refr_n = 1;
     int refl_c = -1, refr_c = -1;
-    int4 meta = make_int4(0, 0, 0, -1);
-    int n_shadow = 0;
-    if (active) {
-        float t;
-        const Surf s = load_surf(lv, i, t);
-        meta = lv.ray_m[i];
-        const float4 ro = lv.ray_o[i], rd = lv.ray_d[i];
-        const f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
-        time = ro.w;
-        if (s.object < 0) {                                            // miss: outColor = background (Q10)
-            if (sc.p.bg_texture >= 0) L = texture_rgb(sc, sc.textures[sc.p.bg_texture], 0.0f, 0.0f, 0.0f);
-            else L = ld3(sc.p.background);
-        } else {
-            flags = NODE_HIT;
-            const DevObject &ob = sc.objects[s.object];
-            const rt_material &m = sc.materials[ob.material];
-            if (replaces_all(sc, ob)) {
-                L = texture_rgb(sc, sc.textures[ob.tex_color], s.u, s.v, 0.0f);
-            } else {
-                const bool internal = meta.w >= 0 && meta.w == s.object;
-                const f3 to_viewer = normalize3(o - s.ip);             // LightContributionCalculator.cpp:75
-                if (!internal) {                                       // ProcessLights :98-124
-                    f3 all = mk3(0, 0, 0);
-                    all = all + ld3(sc.p.ambient) * ld3(m.ka);
-                    const int nl = sc.p.n_lights;
-                    for (int l = 0; l < nl; ++l) {
-                        const int k = i * nl + l;
-                        f3 c = mk3(0, 0, 0);
-                        ++n_shadow;
-                        if (!sb.occluded[k]) {
-                            const float4 sd = sb.d[k];
-                            const f3 to_light = mk3(sd.x, sd.y, sd.z);
-                            const f3 kd = diffuse_coefficient(sc, m, ob.tex_color, s);
-                            c = brdf_eval(m, to_light, to_viewer, s.n, kd, ld3(m.ks), m.refraction_index) * light_intensity(sc.lights[l], to_light, sd.w) * 1.0f;
-                        }
-                        all = all + c;
-                    }
-                    L = L + all;
+    if (recurse && depth < sc.p.max_depth) {
+        const rt_material &m = sc.materials[mat_index];
+        if (m.type != RT_MAT_DEFAULT) {
+            f3 N = normalize3(s.n);
+            const float se = sc.p.shadow_eps;
+            float fraction = 0;
+            if (m.type == RT_MAT_DIELECTRIC || m.type == RT_MAT_CONDUCTOR) {
+                // ComputeFresnel (:203-228)
+                float n_out = ray_d.w, n_in = m.refraction_index;
+                if (internal) n_in = 1;
+                float corr = clampf(dot3(d, N), -1, 1);
+                if (corr > 0) {
+                    if (m.type == RT_MAT_CONDUCTOR) { float sw = n_out; n_out = n_in; n_in = sw; }
+                    N = -N;
+                } else corr = -corr;
+                const float sin1 = sqrtf(1 - corr * corr);
+                const float sin2 = (n_out * sin1) / n_in;
+                const float cos2 = sqrtf(1 - sin2 * sin2);
+                if (m.type == RT_MAT_DIELECTRIC) {             // Material.cpp:13-24
+                    const float n2c1 = n_in * corr, n1c2 = n_out * cos2;
+                    const float rpll = (n2c1 - n1c2) / (n2c1 + n1c2);
+                    const float n1c1 = n_out * corr, n2c2 = n_in * cos2;
+                    const float rperp = (n1c1 - n2c2) / (n1c1 + n2c2);
+                    fraction = 0.5f * (rpll * rpll + rperp * rperp);
+                } else {                                       // Material.cpp:26-38 (Q13)
+                    const float n1 = m.refraction_index;
+                    const float c2 = corr * corr, nk = n1 * n1 + m.absorption_index * m.absorption_index, n2c = 2 * n1 * corr;
+                    const float Rs = (nk - n2c + c2) / (nk + n2c + c2), Rp = (nk * c2 - n2c + 1) / (nk * c2 + n2c + 1);
+                    fraction = 0.5f * (Rs + Rp);
                 }
-                if (depth < sc.p.max_depth && m.type != RT_MAT_DEFAULT) {
-                    // RecursiveComputation (RecursiveComputation.cpp:25-30)
-                    f3 N = normalize3(s.n);
-                    const float se = sc.p.shadow_eps;
-                    float fraction = 0;
-                    if (m.type == RT_MAT_DIELECTRIC || m.type == RT_MAT_CONDUCTOR) {
-                        // ComputeFresnel (:203-228)
-                        float n_out = rd.w, n_in = m.refraction_index;
-                        if (internal) n_in = 1;
-                        float corr = clampf(dot3(d, N), -1, 1);
-                        if (corr > 0) {
-                            if (m.type == RT_MAT_CONDUCTOR) { float sw = n_out; n_out = n_in; n_in = sw; }
-                            N = -N;
-                        } else corr = -corr;
-                        const float sin1 = sqrtf(1 - corr * corr);
-                        const float sin2 = (n_out * sin1) / n_in;
-                        const float cos2 = sqrtf(1 - sin2 * sin2);
-                        if (m.type == RT_MAT_DIELECTRIC) {             // Material.cpp:13-24
-                            const float n2c1 = n_in * corr, n1c2 = n_out * cos2;
-                            const float rpll = (n2c1 - n1c2) / (n2c1 + n1c2);
-                            const float n1c1 = n_out * corr, n2c2 = n_in * cos2;
-                            const float rperp = (n1c1 - n2c2) / (n1c1 + n2c2);
-                            fraction = 0.5f * (rpll * rpll + rperp * rperp);
-                        } else {                                       // Material.cpp:26-38 (Q13)
-                            const float n1 = m.refraction_index;
-                            const float c2 = corr * corr, nk = n1 * n1 + m.absorption_index * m.absorption_index, n2c = 2 * n1 * corr;
-                            const float Rs = (nk - n2c + c2) / (nk + n2c + c2), Rp = (nk * c2 - n2c + 1) / (nk * c2 + n2c + 1);
-                            fraction = 0.5f * (Rs + Rp);
-                        }
-                        // ComputeRefractionParameters (:181-201), PerformRefraction (:154-179) (Q14)
-                        const float param = n_out / n_in;
-                        const float cost = 1 - corr * corr;
-                        const float det = 1 - param * param * cost;
-                        if (det >= 0) {
-                            has_refr = true;
-                            refr_d = normalize3((d + N * corr) * (param)-N * sqrtf(det));
-                            refr_o = s.ip + -N * se;
-                            if (!internal) { refr_n = m.refraction_index; refr_c = s.object; }
-                            else { refr_n = 1.0f; refr_c = -1; }
-                        } else if (internal) fraction = 1;
-                        refr_coef = 1 - fraction;
-                    }
-                    // reflection ray (:62-122)
-                    const f3 to_viewer2 = normalize3(o - s.ip);
-                    f3 vrd = normalize3(N * 2.0f * dot3(to_viewer2, N) - to_viewer2);
-                    if (m.type != RT_MAT_DIELECTRIC && m.roughness > 0) {   // glossy tilt (Q15); the dielectric path does not call it
-                        const int mi = fabsf(vrd.x) < fabsf(vrd.y) ? (fabsf(vrd.x) < fabsf(vrd.z) ? 0 : 2) : (fabsf(vrd.y) < fabsf(vrd.z) ? 1 : 2);
-                        f3 rp = vrd;
-                        if (mi == 0) rp.x = 1.0f; else if (mi == 1) rp.y = 1.0f; else rp.z = 1.0f;
-                        rp = normalize3(rp);
-                        const f3 u = normalize3(cross3(vrd, rp));
-                        const f3 v = normalize3(cross3(vrd, u));
-                        double uu[4];
-                        rng_slot(cam.seed, (unsigned)meta.x, (unsigned)meta.y, (unsigned)meta.z, SLOT_GLOSSY, uu);
-                        const f3 r1 = (float)uni(uu[0], -0.5, 0.5) * u;
-                        const f3 r2 = (float)uni(uu[1], -0.5, 0.5) * v;
-                        vrd = normalize3(vrd + m.roughness * (r1 + r2));
-                    }
-                    has_refl = true;
-                    refl_o = s.ip + N * se;
-                    refl_d = vrd;
-                    refl_n = rd.w; refl_c = meta.w;                    // inherits currMat / currShape (Q26)
-                    if (m.type == RT_MAT_MIRROR) { mrc = ld3(m.km); refl_coef = m.degamma ? 2.2f : 1.0f; flags |= NODE_REFL_MRC; }
-                    else if (m.type == RT_MAT_CONDUCTOR) { mrc = ld3(m.km); refl_coef = fraction; flags |= NODE_REFL_MRC; }
-                    else {
-                        refl_coef = fraction; flags |= NODE_REFL_ALWAYS;
-                        if (internal) {                                // GetDielectricPowerAbsorptionParameter (:143-152, Q12)
-                            const f3 ac = ld3(m.ac);
-                            const float distance = (s.ip.x - o.x) / d.x;
-                            const float ecoeff = expf(-(0.01f * distance));
-                            absorb = ecoeff * mk3(expf(-ac.x * distance), expf(-ac.y * distance), expf(-ac.z * distance));
-                            flags |= NODE_ABSORB;
-                        }
-                    }
+                // ComputeRefractionParameters (:181-201), PerformRefraction (:154-179) (Q14)
+                const float param = n_out / n_in;
+                const float cost = 1 - corr * corr;
+                const float det = 1 - param * param * cost;
+                if (det >= 0) {
+                    has_refr = true;
+                    refr_d = normalize3((d + N * corr) * (param)-N * sqrtf(det));
+                    refr_o = s.ip + -N * se;
+                    if (!internal) { refr_n = m.refraction_index; refr_c = s.object; }
+                    else { refr_n = 1.0f; refr_c = -1; }
+                } else if (internal) fraction = 1;
+                refr_coef = 1 - fraction;
+            }
+            // reflection ray (:62-122)
+            const f3 to_viewer2 = normalize3(o - s.ip);
+            f3 vrd = normalize3(N * 2.0f * dot3(to_viewer2, N) - to_viewer2);
+            if (m.type != RT_MAT_DIELECTRIC && m.roughness > 0) {   // glossy tilt (Q15); the dielectric path does not call it
+                const int mi = fabsf(vrd.x) < fabsf(vrd.y) ? (fabsf(vrd.x) < fabsf(vrd.z) ? 0 : 2) : (fabsf(vrd.y) < fabsf(vrd.z) ? 1 : 2);
+                f3 rp = vrd;
+                if (mi == 0) rp.x = 1.0f; else if (mi == 1) rp.y = 1.0f; else rp.z = 1.0f;
+                rp = normalize3(rp);
+                const f3 u = normalize3(cross3(vrd, rp));
+                const f3 v = normalize3(cross3(vrd, u));
+                double uu[4];
+                rng_slot(cam.seed, (unsigned)meta.x, (unsigned)meta.y, (unsigned)meta.z, SLOT_GLOSSY, uu);
+                const f3 r1 = (float)uni(uu[0], -0.5, 0.5) * u;
+                const f3 r2 = (float)uni(uu[1], -0.5, 0.5) * v;
+                vrd = normalize3(vrd + m.roughness * (r1 + r2));
+            }
+            has_refl = true;
+            refl_o = s.ip + N * se;
+            refl_d = vrd;
+            refl_n = ray_d.w; refl_c = meta.w;                 // inherits currMat / currShape (Q26)
+            if (m.type == RT_MAT_MIRROR) { mrc = ld3(m.km); refl_coef = m.degamma ? 2.2f : 1.0f; flags |= NODE_REFL_MRC; }
+            else if (m.type == RT_MAT_CONDUCTOR) { mrc = ld3(m.km); refl_coef = fraction; flags |= NODE_REFL_MRC; }
+            else {
+                refl_coef = fraction; flags |= NODE_REFL_ALWAYS;
+                if (internal) {                                // GetDielectricPowerAbsorptionParameter (:143-152, Q12)
+                    const f3 ac = ld3(m.ac);
+                    const float distance = (s.ip.x - o.x) / d.x;
+                    const float ecoeff = expf(-(0.01f * distance));
+                    absorb = ecoeff * mk3(expf(-ac.x * distance), expf(-ac.y * distance), expf(-ac.z * distance));
+                    flags |= NODE_ABSORB;
                 }
             }
         }
-        want = (has_refr ? 1 : 0) + (has_refl ? 1 : 0);
     }
-    // ---- compaction into the next level's queue ----
-    int slot = wave_alloc(want, next_count);
+    // compaction into the next level's queue
+    int slot = wave_alloc((has_refr ? 1 : 0) + (has_refl ? 1 : 0), next_count);
     int ci_refr = -1, ci_refl = -1;
-    if (active) {
-        if (has_refr) {
-            ci_refr = slot++;
-            next.ray_o[ci_refr] = make_float4(refr_o.x, refr_o.y, refr_o.z, time);
-            next.ray_d[ci_refr] = make_float4(refr_d.x, refr_d.y, refr_d.z, refr_n);
-            next.ray_m[ci_refr] = make_int4(meta.x, meta.y, meta.z * 2, refr_c);
-        }
-        if (has_refl) {
-            ci_refl = slot++;
-            next.ray_o[ci_refl] = make_float4(refl_o.x, refl_o.y, refl_o.z, time);
-            next.ray_d[ci_refl] = make_float4(refl_d.x, refl_d.y, refl_d.z, refl_n);
-            next.ray_m[ci_refl] = make_int4(meta.x, meta.y, meta.z * 2 + 1, refl_c);
-        }
-        lv.node_a[i] = make_float4(L.x, L.y, L.z, __int_as_float(flags));
-        lv.node_b[i] = make_float4(mrc.x, mrc.y, mrc.z, refl_coef);
-        lv.node_c[i] = make_float4(absorb.x, absorb.y, absorb.z, refr_coef);
-        lv.child[i] = make_int2(ci_refr, ci_refl);
+    if (has_refr) {
+        ci_refr = slot++;
+        next.ray_o[ci_refr] = make_float4(refr_o.x, refr_o.y, refr_o.z, time);
+        next.ray_d[ci_refr] = make_float4(refr_d.x, refr_d.y, refr_d.z, refr_n);
+        next.ray_m[ci_refr] = make_int4(meta.x, meta.y, meta.z * 2, refr_c);
     }
+    if (has_refl) {
+        ci_refl = slot++;
+        next.ray_o[ci_refl] = make_float4(refl_o.x, refl_o.y, refl_o.z, time);
+        next.ray_d[ci_refl] = make_float4(refl_d.x, refl_d.y, refl_d.z, refl_n);
+        next.ray_m[ci_refl] = make_int4(meta.x, meta.y, meta.z * 2 + 1, refl_c);
+    }
+    lv.node_a[i] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(flags));      // k_shade_post adds the local colour
+    lv.node_b[i] = make_float4(mrc.x, mrc.y, mrc.z, refl_coef);
+    lv.node_c[i] = make_float4(absorb.x, absorb.y, absorb.z, refr_coef);
+    lv.child[i] = make_int2(ci_refr, ci_refl);
     if (kind_counts) {      // rays per kind (one "ray" = one closest-hit query): shadow rays of this level, children of the next
-        unsigned a = active ? (unsigned)n_shadow : 0u, b = has_refl ? 1u : 0u, c = has_refr ? 1u : 0u;
-        for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); c += __shfl_down(c, off); }
-        if ((threadIdx.x & 63) == 0) {
-            if (a) atomicAdd(&kind_counts[RT_RAY_SHADOW], (unsigned long long)a);
-            if (b) atomicAdd(&kind_counts[RT_RAY_REFLECT], (unsigned long long)b);
-            if (c) atomicAdd(&kind_counts[RT_RAY_REFRACT], (unsigned long long)c);
+        const unsigned long long live = __ballot(true);
+        unsigned a = lit ? (unsigned)nl : 0u, b = has_refl ? 1u : 0u, c = has_refr ? 1u : 0u;
+        const unsigned ta = __popcll(__ballot(lit)) * (unsigned)nl, tb = __popcll(__ballot(has_refl)), tc = __popcll(__ballot(has_refr));
+        (void)a; (void)b; (void)c;
+        if ((threadIdx.x & 63) == __ffsll((long long)live) - 1) {
+            if (ta) atomicAdd(&kind_counts[RT_RAY_SHADOW], (unsigned long long)ta);
+            if (tb) atomicAdd(&kind_counts[RT_RAY_REFLECT], (unsigned long long)tb);
+            if (tc) atomicAdd(&kind_counts[RT_RAY_REFRACT], (unsigned long long)tc);
         }
     }
 }
-void rt_launch_shade_post(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, ShadowBuf sb, LevelBuf next, int depth,
-                          int *next_count, unsigned long long *kind_counts) {
+void rt_launch_shade_pre(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, ShadowBuf sb, LevelBuf next, int depth,
+                         int *next_count, unsigned long long *kind_counts) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_shade_post, dim3((n + 255) / 256), dim3(256), 0, s, sc, cam, lv, n, sb, next, depth, next_count, kind_counts);
+    hipLaunchKernelGGL(k_shade_pre, dim3((n + 255) / 256), dim3(256), 0, s, sc, cam, lv, n, sb, next, depth, next_count, kind_counts);
+}
+
+// After the shadow rays of the level are traced: the local colour of every hit (ProcessLights, LightContributionCalculator.cpp:98-124),
+// the background for misses, the texture for replace_all decals.
+__global__ __launch_bounds__(256) void k_shade_post(DevScene sc, DevCamera cam, LevelBuf lv, int n, ShadowBuf sb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float t;
+    const Surf s = load_surf(lv, i, t);
+    f3 L = mk3(0, 0, 0);
+    if (s.object < 0) {                                            // miss: outColor = background (Q10)
+        if (sc.p.bg_texture >= 0) L = texture_rgb(sc, sc.textures[sc.p.bg_texture], 0.0f, 0.0f, 0.0f);
+        else L = ld3(sc.p.background);
+    } else {
+        const DevObject &ob = sc.objects[s.object];
+        const rt_material &m = sc.materials[ob.material];
+        if (replaces_all(sc, ob)) {
+            L = texture_rgb(sc, sc.textures[ob.tex_color], s.u, s.v, 0.0f);
+        } else {
+            const int4 meta = lv.ray_m[i];
+            const bool internal = meta.w >= 0 && meta.w == s.object;
+            if (!internal) {                                       // ProcessLights :98-124
+                const float4 ro = lv.ray_o[i];
+                const f3 to_viewer = normalize3(mk3(ro.x, ro.y, ro.z) - s.ip);             // LightContributionCalculator.cpp:75
+                f3 all = mk3(0, 0, 0);
+                all = all + ld3(sc.p.ambient) * ld3(m.ka);
+                const int nl = sc.p.n_lights;
+                for (int l = 0; l < nl; ++l) {
+                    const int k = i * nl + l;
+                    f3 c = mk3(0, 0, 0);
+                    if (!sb.occluded[k]) {
+                        const float4 sd = sb.ldir[k];
+                        const f3 to_light = mk3(sd.x, sd.y, sd.z);
+                        const f3 kd = diffuse_coefficient(sc, m, ob.tex_color, s);
+                        c = brdf_eval(m, to_light, to_viewer, s.n, kd, ld3(m.ks), m.refraction_index) * light_intensity(sc.lights[l], to_light, sd.w) * 1.0f;
+                    }
+                    all = all + c;
+                }
+                L = L + all;
+            }
+        }
+    }
+    float4 a = lv.node_a[i];
+    a.x = L.x; a.y = L.y; a.z = L.z;
+    lv.node_a[i] = a;
+}
+void rt_launch_shade_post(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, ShadowBuf sb) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_shade_post, dim3((n + 255) / 256), dim3(256), 0, s, sc, cam, lv, n, sb);
 }
 
 // Backward sweep: colour(ray) = local + children, in the association order of RecursiveComputation.cpp:62-69,130-141,172-173.

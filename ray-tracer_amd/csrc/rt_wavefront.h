@@ -41,11 +41,15 @@ enum {
     NODE_ABSORB = 8          // Beer absorption multiplies the accumulated colour (Q12)
 };
 
+// Shadow rays of one level.  Results and light vectors are indexed by SLOT = hit * n_lights + light; the rays themselves
+// sit in a compact queue (only lit hits cast them) whose length is counted on the device.
 struct ShadowBuf {
-    float4 *o;          // origin.xyz, time
-    float4 *d;          // direction.xyz, distance to the light
-    float4 *ipref;      // the shaded point ip.xyz, active flag (0 = no shadow ray for this slot)
-    int *occluded;      // result: 1 = an object lies between point and light (Q7)
+    float4 *o;          // queue: origin.xyz, time
+    float4 *d;          // queue: direction.xyz, distance to the light
+    float4 *ipref;      // queue: the shaded point ip.xyz, slot (int bits)
+    int *count;         // queue length (device counter, zeroed per batch)
+    float4 *ldir;       // slot: direction to the light, distance (read by shade_post)
+    int *occluded;      // slot: 1 = an object lies between point and light (Q7)
     int capacity;
 };
 
@@ -61,15 +65,22 @@ struct DevCamera {
 
 struct DevCounters {        // accumulated with atomics when counting is enabled
     unsigned long long node_visits, box_tests, tri_tests, sphere_tests;
+    // lane-occupancy diagnostics of the persistent traversal (lane-summed; printed when RT_TRACE_DEBUG is set):
+    // 0 outer iterations x64, 1 lanes holding a ray, 2 refill rounds x64, 3 lanes refilled, 4 node steps x64, 5 lanes stepping,
+    // 6 leaf primitive iterations x64, 7 lanes testing a primitive, 8 exact-slab fallback rounds x64, 9 lanes needing it
+    unsigned long long dbg[2][10];   // [closest | shadow]
+    unsigned long long hist[32];      // rays by floor(log2(node steps))+1, [closest 16 | shadow 16]
 };
 
 void rt_launch_raygen(hipStream_t s, const DevCamera &cam, const int *pixel_list, int first_pixel, int n_samples, LevelBuf lv);
-// fetch_counter: a zeroed int in device memory, private to the launch (the persistent waves draw ray indices from it)
-void rt_launch_trace(hipStream_t s, const DevScene &sc, LevelBuf lv, int n, int *fetch_counter, int *overflow_stack, DevCounters *counters);
-void rt_launch_trace_shadow(hipStream_t s, const DevScene &sc, ShadowBuf sb, int n, int *fetch_counter, int *overflow_stack, DevCounters *counters);
+// fetch_counter: a zeroed int in device memory, private to the launch (the persistent waves draw ray indices from it).
+// One launch traces lv's n_closest rays and the shadow queue sb (length on the device, at most shadow_bound; 0 = none).
+void rt_launch_trace(hipStream_t s, const DevScene &sc, LevelBuf lv, int n_closest, ShadowBuf sb, int shadow_bound, int *fetch_counter,
+                     int *overflow_stack, DevCounters *counters);
 void rt_launch_trace_batch(hipStream_t s, const DevScene &sc, const rt_ray *rays, rt_hit *hits, int n, int *fetch_counter, int *overflow_stack, DevCounters *counters);
-void rt_launch_shade_pre(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, ShadowBuf sb);
-void rt_launch_shade_post(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, ShadowBuf sb, LevelBuf next, int depth, int *next_count, unsigned long long *ray_kind_counts);
+void rt_launch_shade_pre(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, ShadowBuf sb, LevelBuf next, int depth,
+                         int *next_count, unsigned long long *ray_kind_counts);
+void rt_launch_shade_post(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, ShadowBuf sb);
 void rt_launch_backward(hipStream_t s, LevelBuf lv, int n, LevelBuf next, int has_next);
 void rt_launch_resolve(hipStream_t s, const DevCamera &cam, const int *pixel_list, int first_pixel, int n_pixels, LevelBuf lv0, int compact,
                        float *hdr, int *prim_id, float *prim_t);
