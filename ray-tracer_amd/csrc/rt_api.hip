@@ -472,7 +472,7 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
             if ((size_t)n * 2 > 0x3fffffff) { c->error = "ray queue too large; lower max_batch_samples"; return RT_ERR_TOO_LARGE; }
             HIP_TRY(c, nx.ensure((size_t)n * 2));
         }
-        rt_launch_shade_pre(st, c->dev, dc, lm.view(), n, shadow_view(ln, k), nx.view(), k, counts + k + 1, c->d_kind.p);
+        rt_launch_shade_pre(st, c->dev, dc, lm.view(), n, shadow_view(ln, k), nx.view(), k, counts + k + 1, stats ? c->d_kind.p : nullptr);
         if (k < max_depth) {
             HIP_TRY(c, hipMemcpyAsync(ln.h_count, counts + k + 1, sizeof(int), hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipEventRecord(ln.ev_count, st));

@@ -880,29 +880,18 @@ __device__ __forceinline__ bool replaces_all(const DevScene &sc, const DevObject
     return ob.tex_color >= 0 && sc.textures[ob.tex_color].decal == RT_DECAL_REPLACE_ALL;
 }
 
-// wave64 compaction: every lane asks for `want` (0..2) slots; one atomic per wave reserves the total; returns the
-// first slot of this lane.  __ballot is 64 bits wide on gfx950.
-__device__ __forceinline__ int wave_alloc(int want, int *counter) {
-    const int lane = threadIdx.x & 63;
-    const unsigned long long m1 = __ballot(want >= 1), m2 = __ballot(want >= 2);
-    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int prefix = __popcll(m1 & below) + __popcll(m2 & below);
-    const int total = __popcll(m1) + __popcll(m2);
-    int base = 0;
-    const int leader = __ffsll((long long)__ballot(true)) - 1;      // first lane still executing (lanes >= n have returned)
-    if (lane == leader && total > 0) base = atomicAdd(counter, total);
-    base = __shfl(base, leader);
-    return base + prefix;
-}
-
 // Per hit, right after the closest-hit trace of level `depth`: complete the hit record, apply the normal texture, emit one
 // shadow ray per light into the compact shadow queue, and spawn the reflection / refraction children into level depth+1
 // (RecursiveComputation.cpp) together with the coefficients the backward sweep folds them with.  Nothing here needs the
 // shadow results, so the children of this level and the shadow rays of this level are traced by ONE launch.
 __global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, LevelBuf lv, int n, ShadowBuf sb, LevelBuf next, int depth,
-                                                   int *next_count, unsigned long long *kind_counts) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+                                                   int *next_count) {
+    // Queue space is reserved once per 256-thread block (two atomics per block: same-address atomics from every wave cost
+    // ~6 ns each, chip-wide serial).  Inactive threads of the last block take part in the barriers with lit = false, no children.
+    __shared__ int s_lit[4], s_child[4], s_base[2];
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i0 < n;
+    const int i = active ? i0 : n - 1;          // inactive threads recompute the last ray and write nothing
     const int nl = sc.p.n_lights;
     const int4 meta = lv.ray_m[i];
     const float4 ray_o = lv.ray_o[i], ray_d = lv.ray_d[i];
@@ -916,8 +905,10 @@ __global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, L
         HitOut h;
         finalize_hit(sc, o, d, time, best, h);
         s.ip = h.ip; s.n = h.n; s.u = h.u; s.v = h.v; s.theta = h.theta; s.phi = h.phi; s.shape = h.shape; s.object = h.object; s.prim = h.prim;
-        lv.hit0[i] = make_float4(h.t, __int_as_float(h.shape), __int_as_float(h.object), __int_as_float(h.prim));
-        lv.hit3[i] = make_float4(h.theta, h.phi, 0.0f, 0.0f);
+        if (active) {
+            lv.hit0[i] = make_float4(h.t, __int_as_float(h.shape), __int_as_float(h.object), __int_as_float(h.prim));
+            lv.hit3[i] = make_float4(h.theta, h.phi, 0.0f, 0.0f);
+        }
     }
     bool lit = s.object >= 0, recurse = false;
     const bool internal = s.object >= 0 && meta.w >= 0 && meta.w == s.object;      // IsInternalReflection (Q26)
@@ -932,23 +923,10 @@ __global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, L
             if (internal) lit = false;
         }
     }
-    lv.hit1[i] = make_float4(s.ip.x, s.ip.y, s.ip.z, s.n.x);
-    lv.hit2[i] = make_float4(s.n.y, s.n.z, s.u, s.v);
-
-    // ---- shadow rays: COMPACT queue (one wave-wide reservation per light: a wave's rays towards one light sit together,
-    // which is also the coherent order); the result is written to the ray's slot (hit i, light l) by the trace kernel.
-    for (int l = 0; l < nl; ++l) {
-        const int k = i * nl + l;
-        const int q = wave_alloc(lit ? 1 : 0, sb.count);
-        if (!lit) { sb.occluded[k] = 0; continue; }
-        f3 to_light; float dist;
-        light_vars(sc.lights[l], l, s.ip, cam.seed, meta, to_light, dist);
-        const f3 so = s.ip + s.n * sc.p.shadow_eps;                    // LightContributionCalculator.cpp:133
-        sb.ldir[k] = make_float4(to_light.x, to_light.y, to_light.z, dist);
-        sb.o[q] = make_float4(so.x, so.y, so.z, time);
-        sb.d[q] = make_float4(to_light.x, to_light.y, to_light.z, dist);
-        sb.ipref[q] = make_float4(s.ip.x, s.ip.y, s.ip.z, __int_as_float(k));
-    }
+    if (active) {
+        lv.hit1[i] = make_float4(s.ip.x, s.ip.y, s.ip.z, s.n.x);
+        lv.hit2[i] = make_float4(s.n.y, s.n.z, s.u, s.v);
+    } else { lit = false; recurse = false; }
 
     // ---- children (RecursiveComputation.cpp:25-30) ----
     f3 mrc = mk3(0, 0, 0), absorb = mk3(1, 1, 1);
@@ -1035,8 +1013,37 @@ __global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, L
             }
         }
     }
-    // compaction into the next level's queue
-    int slot = wave_alloc((has_refr ? 1 : 0) + (has_refl ? 1 : 0), next_count);
+    // ---- block-wide reservation in the shadow queue and in the next level's queue ----
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const unsigned long long m_lit = __ballot(lit), m1 = __ballot(has_refr || has_refl), m2 = __ballot(has_refr && has_refl);
+    if (lane == 0) { s_lit[wave] = __popcll(m_lit); s_child[wave] = __popcll(m1) + __popcll(m2); }
+    __syncthreads();
+    const int block_lit = s_lit[0] + s_lit[1] + s_lit[2] + s_lit[3];
+    if (threadIdx.x == 0) {
+        const int block_child = s_child[0] + s_child[1] + s_child[2] + s_child[3];
+        s_base[0] = (block_lit && nl) ? atomicAdd(sb.count, block_lit * nl) : 0;
+        s_base[1] = block_child ? atomicAdd(next_count, block_child) : 0;
+    }
+    __syncthreads();
+    int lit_rank = __popcll(m_lit & below), slot = s_base[1] + __popcll(m1 & below) + __popcll(m2 & below);
+    for (int w = 0; w < wave; ++w) { lit_rank += s_lit[w]; slot += s_child[w]; }
+
+    // shadow rays: COMPACT queue; the block's rays towards one light sit together (also the coherent order); the result
+    // is written to the ray's slot (hit i, light l) by the trace kernel.
+    for (int l = 0; l < nl && active; ++l) {
+        const int k = i * nl + l;
+        if (!lit) { sb.occluded[k] = 0; continue; }
+        const int q = s_base[0] + l * block_lit + lit_rank;
+        f3 to_light; float dist;
+        light_vars(sc.lights[l], l, s.ip, cam.seed, meta, to_light, dist);
+        const f3 so = s.ip + s.n * sc.p.shadow_eps;                    // LightContributionCalculator.cpp:133
+        sb.ldir[k] = make_float4(to_light.x, to_light.y, to_light.z, dist);
+        sb.o[q] = make_float4(so.x, so.y, so.z, time);
+        sb.d[q] = make_float4(to_light.x, to_light.y, to_light.z, dist);
+        sb.ipref[q] = make_float4(s.ip.x, s.ip.y, s.ip.z, __int_as_float(k));
+    }
+    if (!active) return;
     int ci_refr = -1, ci_refl = -1;
     if (has_refr) {
         ci_refr = slot++;
@@ -1054,22 +1061,29 @@ __global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, L
     lv.node_b[i] = make_float4(mrc.x, mrc.y, mrc.z, refl_coef);
     lv.node_c[i] = make_float4(absorb.x, absorb.y, absorb.z, refr_coef);
     lv.child[i] = make_int2(ci_refr, ci_refl);
-    if (kind_counts) {      // rays per kind (one "ray" = one closest-hit query): shadow rays of this level, children of the next
-        const unsigned long long live = __ballot(true);
-        unsigned a = lit ? (unsigned)nl : 0u, b = has_refl ? 1u : 0u, c = has_refr ? 1u : 0u;
-        const unsigned ta = __popcll(__ballot(lit)) * (unsigned)nl, tb = __popcll(__ballot(has_refl)), tc = __popcll(__ballot(has_refr));
-        (void)a; (void)b; (void)c;
-        if ((threadIdx.x & 63) == __ffsll((long long)live) - 1) {
-            if (ta) atomicAdd(&kind_counts[RT_RAY_SHADOW], (unsigned long long)ta);
-            if (tb) atomicAdd(&kind_counts[RT_RAY_REFLECT], (unsigned long long)tb);
-            if (tc) atomicAdd(&kind_counts[RT_RAY_REFRACT], (unsigned long long)tc);
-        }
+}
+// Rays per kind of a level (one "ray" = one closest-hit query), only when the caller asked for rt_stats: the shadow rays and
+// the children this level spawned, from the child table (block reduction, one atomic per block and kind).
+__global__ __launch_bounds__(256) void k_count_kinds(LevelBuf lv, int n, const int *shadow_count, unsigned long long *kind_counts) {
+    __shared__ unsigned s_r[4], s_t[4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int2 ch = make_int2(-1, -1);
+    if (i < n) ch = lv.child[i];
+    const unsigned long long mr = __ballot(ch.x >= 0), ml = __ballot(ch.y >= 0);
+    if ((threadIdx.x & 63) == 0) { s_t[threadIdx.x >> 6] = __popcll(mr); s_r[threadIdx.x >> 6] = __popcll(ml); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = s_t[0] + s_t[1] + s_t[2] + s_t[3], r = s_r[0] + s_r[1] + s_r[2] + s_r[3];
+        if (r) atomicAdd(&kind_counts[RT_RAY_REFLECT], (unsigned long long)r);
+        if (t) atomicAdd(&kind_counts[RT_RAY_REFRACT], (unsigned long long)t);
+        if (blockIdx.x == 0 && shadow_count) atomicAdd(&kind_counts[RT_RAY_SHADOW], (unsigned long long)*shadow_count);
     }
 }
 void rt_launch_shade_pre(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, ShadowBuf sb, LevelBuf next, int depth,
                          int *next_count, unsigned long long *kind_counts) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_shade_pre, dim3((n + 255) / 256), dim3(256), 0, s, sc, cam, lv, n, sb, next, depth, next_count, kind_counts);
+    hipLaunchKernelGGL(k_shade_pre, dim3((n + 255) / 256), dim3(256), 0, s, sc, cam, lv, n, sb, next, depth, next_count);
+    if (kind_counts) hipLaunchKernelGGL(k_count_kinds, dim3((n + 255) / 256), dim3(256), 0, s, lv, n, sb.count, kind_counts);
 }
 
 // After the shadow rays of the level are traced: the local colour of every hit (ProcessLights, LightContributionCalculator.cpp:98-124),
