@@ -551,6 +551,8 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
                 for (int k = 0; k < 10; ++k) fprintf(stderr, " %llu", hc.dbg[q][k]);
                 fprintf(stderr, "\n[rt] steps histogram (log2 buckets):");
                 for (int k = 0; k < 16; ++k) fprintf(stderr, " %llu", hc.hist[q * 16 + k]);
+                fprintf(stderr, "\n[rt] ns per node step by bucket:");
+                for (int k = 0; k < 16; ++k) fprintf(stderr, " %.0f", hc.hist[64 + q * 16 + k] ? 10.0 * hc.hist[32 + q * 16 + k] / hc.hist[64 + q * 16 + k] : 0.0);
                 fprintf(stderr, "\n");
             }
         }

@@ -277,7 +277,14 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
                     if (!dup) hs.prims.push_back(rec);
                 }
                 lf.count = (int32_t)hs.prims.size() - lf.start;
-                ref[n] = ~(int32_t)hs.leaves.size();
+                // leaf reference: ~(count << 26 | start) so that the traversal needs no DevLeaf fetch; leaves that do not
+                // fit (more than 31 primitives, start >= 2^26) keep count = 0 and carry the leaf index instead
+                if (lf.count >= 1 && lf.count <= DEV_LEAF_MAX_PACKED && lf.start < (1 << DEV_LEAF_START_BITS))
+                    ref[n] = ~(int32_t)(((uint32_t)lf.count << DEV_LEAF_START_BITS) | (uint32_t)lf.start);
+                else {
+                    if (hs.leaves.size() >= (size_t)(1 << DEV_LEAF_START_BITS)) { err = "too many BVH leaves for the packed leaf reference"; return RT_ERR_TOO_LARGE; }
+                    ref[n] = ~(int32_t)hs.leaves.size();
+                }
                 hs.leaves.push_back(lf);
                 hs.ref_leaf_range.push_back(bn[n].start); hs.ref_leaf_range.push_back(bn[n].end);
                 const Aabb &b = bn[n].box;

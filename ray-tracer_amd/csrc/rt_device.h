@@ -4,8 +4,9 @@
 // L2 line exactly one):
 //   DevNode  — one per INTERNAL node; holds BOTH child boxes so one fetch decides both descents
 //   DevPrim  — one per leaf primitive reference, stored in leaf order (a leaf is a contiguous run)
-// Leaves are not nodes: a child reference < 0 is ~leafIndex into DevLeaf[] and leafIndex is the leaf's
-// position in the reference tree's left-to-right DFS order, which is the tie-break key of Q4.
+// Leaves are not nodes: a child reference < 0 is ~(count << 26 | start), the leaf's run inside DevPrim[] (count = 0: the
+// low bits are an index into DevLeaf[] instead, for leaves that do not fit).  DevPrim[] is stored in the reference
+// tree's left-to-right DFS leaf order, so `start` is also the tie-break key of Q4.
 #ifndef RT_DEVICE_H_
 #define RT_DEVICE_H_
 
@@ -16,11 +17,13 @@
 struct alignas(64) DevNode {
     float lmin[3], lmax[3];   // left child box   (BVHNode::bbox of left,  reference src/BVHTree.h:20)
     float rmin[3], rmax[3];   // right child box
-    int32_t left, right;      // >= 0: internal node index, < 0: ~leafIndex
+    int32_t left, right;      // >= 0: internal node index, < 0: leaf reference (above)
     int32_t _pad[2];
 };
 static_assert(sizeof(DevNode) == 64, "DevNode must be 64 bytes");
 
+#define DEV_LEAF_START_BITS 26
+#define DEV_LEAF_MAX_PACKED 31
 struct DevLeaf {
     int32_t start, count;     // run inside DevPrim[]
 };
@@ -65,7 +68,7 @@ struct DevSceneParams {
     float ambient[3];
     int32_t bg_texture;
     int32_t n_lights, n_materials, n_textures;
-    int32_t root;             // >= 0 internal node index, < 0 ~leafIndex, RT_NO_ROOT when the scene is empty
+    int32_t root;             // >= 0 internal node index, < 0 leaf reference, RT_NO_ROOT when the scene is empty
     float root_min[3], root_max[3];
     float prune_err;          // absolute bound used to keep t-pruning conservative
     int32_t bvh_depth;

@@ -85,28 +85,36 @@ __device__ __forceinline__ void object_matrices(const DevObject &ob, float time,
     }
 }
 
-template <bool MOTION>
-__device__ __noinline__ void enter_object(const DevScene &sc, int obj, f3 o, f3 d, float time, ObjXf &x) {
+// moving object: the matrices are rebuilt for the ray's time (kept out of line: inverse + transposes)
+__device__ __noinline__ void enter_object_motion(const DevScene &sc, int obj, f3 o, f3 d, float time, ObjXf *out) {
     const DevObject &ob = sc.objects[obj];
+    float M[16], inv[16];
+    int flags;
+    object_matrices(ob, time, M, inv, flags);
+    out->id = obj; out->flags = flags;
+    out->o = matT_mul_xyz(inv, o.x, o.y, o.z, 1.0f);
+    out->d = normalize3(matT_mul_xyz(inv, d.x, d.y, d.z, 0.0f));
+}
+template <bool MOTION>
+__device__ __forceinline__ void enter_object(const DevScene &sc, int obj, f3 o, f3 d, float time, ObjXf &x) {
+    const DevObject &ob = sc.objects[obj];
+    const int flags = ob.flags;
+    if (MOTION && (flags & DEV_OBJ_HAS_XFORM) && (flags & DEV_OBJ_MOTION)) {
+        ObjXf tmp;                                                    // the only ObjXf that lives in memory
+        enter_object_motion(sc, obj, o, d, time, &tmp);
+        x.id = tmp.id; x.flags = tmp.flags; x.o = tmp.o; x.d = tmp.d;
+        return;
+    }
     x.id = obj;
-    if (!(ob.flags & DEV_OBJ_HAS_XFORM)) {                            // standalone <Triangle>: objTransform == nullptr (Shape.cpp:69)
-        x.flags = ob.flags | DEV_OBJ_IDENTITY;
+    if (!(flags & DEV_OBJ_HAS_XFORM)) {                               // standalone <Triangle>: objTransform == nullptr (Shape.cpp:69)
+        x.flags = flags | DEV_OBJ_IDENTITY;
         x.o = o; x.d = d;
         return;
     }
-    if (!MOTION || !(ob.flags & DEV_OBJ_MOTION)) {
-        // Transform::operator()(Ray, obj2world=false): transpose(inv) * (o,1), transpose(inv) * (d,0), renormalise (acmath.h:1053-1069)
-        x.flags = ob.flags;
-        x.o = matT_mul_xyz(ob.inv, o.x, o.y, o.z, 1.0f);
-        x.d = normalize3(matT_mul_xyz(ob.inv, d.x, d.y, d.z, 0.0f));
-        return;
-    }
-    if (MOTION) {
-        float M[16], inv[16];
-        object_matrices(ob, time, M, inv, x.flags);
-        x.o = matT_mul_xyz(inv, o.x, o.y, o.z, 1.0f);
-        x.d = normalize3(matT_mul_xyz(inv, d.x, d.y, d.z, 0.0f));
-    }
+    // Transform::operator()(Ray, obj2world=false): transpose(inv) * (o,1), transpose(inv) * (d,0), renormalise (acmath.h:1053-1069)
+    x.flags = flags;
+    x.o = matT_mul_xyz(ob.inv, o.x, o.y, o.z, 1.0f);
+    x.d = normalize3(matT_mul_xyz(ob.inv, d.x, d.y, d.z, 0.0f));
 }
 
 // object -> world for a hit point of object `obj` (glm mat*vec4(p,1): (m0*x + m1*y) + (m2*z + m3*1)); the matrix is read
@@ -214,24 +222,46 @@ __device__ __forceinline__ int slab_fast(f3 bmin, f3 bmax, f3 o, f3 r, f3 marg, 
 // ----------------------------------------------------------------------------------------------------
 // Persistent wave64 traversal with per-lane ray refill.
 //
-// Rays differ wildly in traversal length (config 2: mean 49 nodes, tail > 500).  With one ray per lane per pass a wave
-// runs as long as its slowest lane: rocprof showed 7-14 % of VALU lanes active.  Here a wave is a persistent worker:
-// whenever lanes are idle it reserves that many ray indices from a global counter (one atomic per wave, __ballot +
-// __popcll prefix) and the idle lanes start new rays while the others continue.  The loop alternates a NODE phase
-// (lanes sitting on an internal node step; lanes that reached a leaf wait) and a LEAF phase (all lanes on a leaf run the
-// primitive tests together), so the long leaf code is executed with many lanes active ("while-while").
+// Rays differ wildly in traversal length (config 2: mean 49 nodes + 7 primitive tests, tail > 400).  A wave is a persistent
+// worker: it owns a chunk of the ray queue (one atomic per TRACE_CHUNK rays) and whenever enough lanes are idle they retire
+// their results and start new rays while the other lanes continue.
+//
+// Every iteration a lane that holds a ray does ONE unit of work: a node step (both child boxes) or one primitive test of
+// the leaf it is in.  Node records and primitive records are both 64 bytes, so the same four 16-byte loads fetch either
+// and an iteration costs one memory round trip whatever mix of states the wave is in.  The kernel is VALU-issue bound,
+// so the expensive primitive path only runs when at least TRI_MIN_LANES lanes wait in a leaf (or nothing else is left to
+// do); retiring and refilling is batched the same way (REFILL_MIN_IDLE).
+//
+// Registers: the hit payload that is only needed at the end (ip, beta, gamma of the leaf-local and of the best candidate)
+// lives in LDS next to the traversal stack.
 //
 // IO policy: load(i, o, d, time) -> false when slot i needs no traversal (result already written);
 //            store(sc, i, best)   writes the result of ray i.
 // ----------------------------------------------------------------------------------------------------
-#define CUR_DONE 0x7ffffffe      // lane finished its ray (stack empty)
-#define NODE_PHASE_MIN_LANES 12  // leave the node phase when fewer lanes than this still sit on internal nodes
+#define CUR_DONE 0x7ffffffe      // lane finished its ray (stack empty), result not yet stored
+#define CUR_IN_LEAF 0x7ffffffd   // lane is walking the primitive run [prim_i, prim_end) of a leaf
 #define TRACE_CHUNK 64           // rays a wave reserves per atomic
-#define REFILL_MIN_IDLE 8        // refill once this many lanes are idle
+#define REFILL_MIN_IDLE 8        // retire + refill once this many lanes are idle
+#define TRI_MIN_LANES 16         // run the primitive path once this many lanes wait in a leaf
+#define LDS_PAYLOAD 10           // floats per lane: ip.xyz, beta, gamma of the leaf-local candidate, then of the best one
+
+struct TraceDbg { unsigned nodes, boxes, tris, sph, v[10]; };
+
+// Traversal stack: LDS_STACK entries per lane in LDS ([entry][thread], conflict-free), deeper entries in a global column.
+// The overflow accesses are volatile so that the compiler keeps two separate paths (ds_* and global_*) instead of one
+// FLAT access through a selected pointer, which would tie every push/pop to both memory counters.
+__device__ __forceinline__ void stack_push(int *lds_col, int *ovf_col, int ovf_stride, int sp, int v) {
+    if (sp < LDS_STACK) lds_col[sp * TRACE_BLOCK] = v;
+    else *(volatile int *)(ovf_col + (size_t)(sp - LDS_STACK) * ovf_stride) = v;
+}
+__device__ __forceinline__ int stack_pop(const int *lds_col, const int *ovf_col, int ovf_stride, int sp) {
+    if (sp < LDS_STACK) return lds_col[sp * TRACE_BLOCK];
+    return *(const volatile int *)(ovf_col + (size_t)(sp - LDS_STACK) * ovf_stride);
+}
 
 template <bool COUNT, bool MOTION, class IO>
-__device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io, int n, int *fetch_counter, int *lds_col, int *ovf_col,
-                                                 int ovf_stride, unsigned &cnt_nodes, unsigned &cnt_boxes, unsigned &cnt_tris, unsigned &cnt_sph, unsigned *dbg, unsigned long long *hist) {
+__device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io, int n, int *fetch_counter, int *lds_col, float *pay,
+                                                 int *ovf_col, int ovf_stride, TraceDbg &dbg, unsigned long long *hist) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const float4 *nodes4 = reinterpret_cast<const float4 *>(sc.nodes);
@@ -240,139 +270,160 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
     const bool no_scene = sc.p.root == RT_NO_ROOT;
 
     bool has_ray = false, exact_only = false;
-    int ray_idx = 0, sp = 0, cur = CUR_DONE, best_leaf = -1;
+    int ray_idx = 0, sp = 0, cur = CUR_DONE, prim_i = 0, prim_end = 0;
+    int best_prim = -1, best_leaf = -1, local_prim = -1, leaf_key = 0;
+    float best_t = FLT_MAX, local_t = FLT_MAX;
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), r = mk3(0, 0, 1), marg = mk3(0, 0, 0);
     float time = 0;
-    Cand best;
-    best.t = FLT_MAX; best.prim = -1; best.ip = mk3(0, 0, 0); best.beta = best.gamma = 0;
     ObjXf xf;
     xf.id = -2; xf.flags = 0; xf.o = o; xf.d = d;
     unsigned ray_steps = 0;
+    unsigned long long ray_t0 = 0;
     bool exhausted = false;          // wave-uniform: the global queue has no more chunks
     int chunk_next = 0, chunk_end = 0;
 
     for (;;) {
-        if (COUNT) { ++dbg[0]; if (has_ray) ++dbg[1]; }
-        // ---------------- refill idle lanes ----------------
-        // The wave owns a chunk [chunk_next, chunk_end) of the queue (one atomic per TRACE_CHUNK rays) and hands its rays to
-        // idle lanes in lane order, once at least REFILL_MIN_IDLE lanes wait (fewer: the ray loads are not worth a pass).
+        if (COUNT) { ++dbg.v[0]; if (has_ray && cur != CUR_DONE) ++dbg.v[1]; }
+        // ---------------- retire finished rays, refill idle lanes (batched) ----------------
         {
-            const unsigned long long idle = __ballot(!has_ray);
+            const bool done = has_ray && cur == CUR_DONE;
+            const unsigned long long idle = __ballot(!has_ray || done);
             const int nidle = __popcll(idle);
-            if (nidle >= REFILL_MIN_IDLE && (!exhausted || chunk_next < chunk_end)) {
-                if (chunk_next >= chunk_end) {
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(fetch_counter, TRACE_CHUNK);
-                    base = __shfl(base, 0);
-                    chunk_next = base;
-                    chunk_end = base + TRACE_CHUNK < n ? base + TRACE_CHUNK : n;
-                    if (base + TRACE_CHUNK >= n) exhausted = true;
+            if (nidle >= REFILL_MIN_IDLE) {
+                if (done) {
+                    if (COUNT && hist) {
+                        const int bk = io.kind(ray_idx) * 16 + (ray_steps ? 32 - __clz(ray_steps) : 0);
+                        atomicAdd(&hist[bk], 1ull);
+                        atomicAdd(&hist[32 + bk], (unsigned long long)(wall_clock64() - ray_t0));     // 100 MHz ticks
+                        atomicAdd(&hist[64 + bk], (unsigned long long)ray_steps);
+                        ray_steps = 0;
+                    }
+                    Cand best;
+                    best.t = best_t; best.prim = best_prim; best.ip = mk3(0, 0, 0); best.beta = best.gamma = 0;
+                    if (best_prim >= 0) {
+                        best.ip = mk3(pay[5 * TRACE_BLOCK], pay[6 * TRACE_BLOCK], pay[7 * TRACE_BLOCK]);
+                        best.beta = pay[8 * TRACE_BLOCK]; best.gamma = pay[9 * TRACE_BLOCK];
+                    }
+                    io.store(sc, ray_idx, best);
+                    has_ray = false;
                 }
-                const int avail = chunk_end > chunk_next ? chunk_end - chunk_next : 0;
-                const int rank = __popcll(idle & lt_mask);
-                if (COUNT) { ++dbg[2]; if (!has_ray && rank < avail) ++dbg[3]; }
-                if (!has_ray && rank < avail) {
-                    const int mine = chunk_next + rank;
-                    if (io.load(mine, o, d, time)) {
-                        ray_idx = mine;
-                        best.t = FLT_MAX; best.prim = -1; best.ip = mk3(0, 0, 0); best.beta = best.gamma = 0;
-                        best_leaf = -1; sp = 0; xf.id = -2;
-                        // Q2: the hit parameter is (ip.x - o.x)/d.x; with d.x == 0 (or NaN) no hit is ever accepted.
-                        bool alive = !no_scene && (d.x != 0.0f);
-                        if (COUNT) ++cnt_boxes;
-                        if (alive) alive = slab_exact(ld3(sc.p.root_min), ld3(sc.p.root_max), o, d);
-                        if (alive) {
-                            r = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                            // a zero / denormal-range direction component: exact slab test everywhere (inf and NaN quotients)
-                            exact_only = !(fabsf(d.y) > 1e-30f && fabsf(d.z) > 1e-30f && fabsf(d.x) > 1e-30f);
-                            const float err = sc.p.prune_err + 2e-4f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z));
-                            marg = mk3(err * fabsf(r.x) * 1.000001f, err * fabsf(r.y) * 1.000001f, err * fabsf(r.z) * 1.000001f);
-                            cur = sc.p.root;
-                            has_ray = true;
-                        } else {
-                            io.store(sc, mine, best);
+                if (!exhausted || chunk_next < chunk_end) {
+                    if (chunk_next >= chunk_end) {
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(fetch_counter, TRACE_CHUNK);
+                        base = __shfl(base, 0);
+                        chunk_next = base;
+                        chunk_end = base + TRACE_CHUNK < n ? base + TRACE_CHUNK : n;
+                        if (base + TRACE_CHUNK >= n) exhausted = true;
+                    }
+                    const int avail = chunk_end > chunk_next ? chunk_end - chunk_next : 0;
+                    const int rank = __popcll(idle & lt_mask);
+                    if (COUNT) { ++dbg.v[2]; if (!has_ray && rank < avail) ++dbg.v[3]; }
+                    if (!has_ray && rank < avail) {
+                        const int mine = chunk_next + rank;
+                        if (io.load(mine, o, d, time)) {
+                            ray_idx = mine;
+                            if (COUNT) ray_t0 = wall_clock64();
+                            best_t = FLT_MAX; best_prim = -1; best_leaf = -1; sp = 0; xf.id = -2; prim_i = prim_end = 0;
+                            // Q2: the hit parameter is (ip.x - o.x)/d.x; with d.x == 0 (or NaN) no hit is ever accepted.
+                            bool alive = !no_scene && (d.x != 0.0f);
+                            if (COUNT) ++dbg.boxes;
+                            if (alive) alive = slab_exact(ld3(sc.p.root_min), ld3(sc.p.root_max), o, d);
+                            if (alive) {
+                                r = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                                // a zero / denormal-range direction component: exact slab test everywhere (inf and NaN quotients)
+                                exact_only = !(fabsf(d.y) > 1e-30f && fabsf(d.z) > 1e-30f && fabsf(d.x) > 1e-30f);
+                                const float err = sc.p.prune_err + 2e-4f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z));
+                                marg = mk3(err * fabsf(r.x) * 1.000001f, err * fabsf(r.y) * 1.000001f, err * fabsf(r.z) * 1.000001f);
+                                cur = sc.p.root;
+                                has_ray = true;
+                            } else {
+                                Cand none;
+                                none.t = FLT_MAX; none.prim = -1; none.ip = mk3(0, 0, 0); none.beta = none.gamma = 0;
+                                io.store(sc, mine, none);
+                            }
                         }
                     }
+                    chunk_next += nidle < avail ? nidle : avail;
                 }
-                chunk_next += nidle < avail ? nidle : avail;
             }
         }
         if (!__any(has_ray)) { if (exhausted && chunk_next >= chunk_end) break; else continue; }
 
-        // ---------------- node phase ----------------
-        for (;;) {
-            const bool at_node = has_ray && cur >= 0 && cur != CUR_DONE;
-            const unsigned long long m = __ballot(at_node);
-            if (m == 0) break;
-            if (__popcll(m) < NODE_PHASE_MIN_LANES && __any(has_ray && cur < 0)) break;   // enough leaf work is waiting
-            if (COUNT) { ++dbg[4]; if (at_node) ++dbg[5]; }
-            if (at_node) {
-                const float4 n0 = nodes4[cur * 4 + 0], n1 = nodes4[cur * 4 + 1], n2 = nodes4[cur * 4 + 2], n3 = nodes4[cur * 4 + 3];
-                float tnl, tnr, lbl, lbr;
-                int sl = slab_fast(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, r, marg, tnl, lbl);
-                int sr = slab_fast(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, r, marg, tnr, lbr);
-                if (exact_only) { sl = 2; sr = 2; lbl = lbr = -FLT_MAX; }
-                if (COUNT) { if (sl == 2 || sr == 2) ++dbg[9]; if (__any(sl == 2 || sr == 2)) ++dbg[8]; }
-                if (sl == 2) sl = slab_exact(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, d) ? 1 : 0;
-                if (sr == 2) sr = slab_exact(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, d) ? 1 : 0;
-                if (COUNT) { ++cnt_nodes; cnt_boxes += 2; ++ray_steps; }
-                const bool hl = sl != 0 && !(lbl > best.t);
-                const bool hr = sr != 0 && !(lbr > best.t);
-                const int left = __float_as_int(n3.x), right = __float_as_int(n3.y);
-                if (hl && hr) {
-                    int nearc = left, farc = right;
-                    if (tnr < tnl) { nearc = right; farc = left; }
-                    if (sp < LDS_STACK) lds_col[sp * TRACE_BLOCK] = farc; else ovf_col[(sp - LDS_STACK) * ovf_stride] = farc;
-                    ++sp;
-                    cur = nearc;
-                } else if (hl) cur = left;
-                else if (hr) cur = right;
-                else if (sp == 0) cur = CUR_DONE;
-                else { --sp; cur = (sp < LDS_STACK) ? lds_col[sp * TRACE_BLOCK] : ovf_col[(sp - LDS_STACK) * ovf_stride]; }
-            }
+        // a lane that arrived at a leaf (root, descent or pop) unpacks its primitive run: no memory round trip of its own
+        if (has_ray && cur < 0) {
+            const unsigned u = (unsigned)~cur;
+            int start = (int)(u & ((1u << DEV_LEAF_START_BITS) - 1)), count = (int)(u >> DEV_LEAF_START_BITS);
+            if (count == 0) { const DevLeaf lf = sc.leaves[start]; start = lf.start; count = lf.count; }
+            prim_i = start; prim_end = start + count; leaf_key = start;
+            local_t = FLT_MAX; local_prim = -1;
+            cur = CUR_IN_LEAF;
         }
 
-        // ---------------- leaf phase ----------------
-        if (COUNT) {
-            int mx = (has_ray && cur < 0) ? sc.leaves[~cur].count : 0;
-            dbg[7] += mx;
-            for (int off = 32; off > 0; off >>= 1) { int other = __shfl_xor(mx, off); mx = other > mx ? other : mx; }
-            dbg[6] += mx;
+        // ---------------- one unit of work per lane: a node step or a primitive test ----------------
+        const bool in_leaf = has_ray && cur == CUR_IN_LEAF;
+        const bool at_node = has_ray && cur >= 0 && cur < CUR_IN_LEAF;
+        const int n_leaf = __popcll(__ballot(in_leaf)), n_node = __popcll(__ballot(at_node));
+        const bool run_tri = n_leaf > 0 && (n_leaf >= TRI_MIN_LANES || n_leaf >= n_node);      // wave-uniform
+        const bool do_tri = in_leaf && run_tri;
+        // every lane loads (idle lanes re-read record 0 of the node array): no merge of loaded and stale registers
+        const float4 *rec = do_tri ? prims4 + 4 * (size_t)prim_i : nodes4 + (at_node ? 4 * (size_t)cur : 0);
+        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+        if (COUNT) { ++dbg.v[4]; if (at_node) ++dbg.v[5]; if (do_tri) ++dbg.v[7]; if (run_tri) ++dbg.v[6]; }
+        if (at_node) {
+            float tnl, tnr, lbl, lbr;
+            int sl = slab_fast(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, r, marg, tnl, lbl);
+            int sr = slab_fast(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, r, marg, tnr, lbr);
+            if (exact_only) { sl = 2; sr = 2; lbl = lbr = -FLT_MAX; }
+            if (COUNT) { if (sl == 2 || sr == 2) ++dbg.v[9]; if (__any(sl == 2 || sr == 2)) ++dbg.v[8]; }
+            if (sl == 2) sl = slab_exact(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, d) ? 1 : 0;
+            if (sr == 2) sr = slab_exact(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, d) ? 1 : 0;
+            if (COUNT) { ++dbg.nodes; dbg.boxes += 2; ++ray_steps; }
+            const bool hl = sl != 0 && !(lbl > best_t);
+            const bool hr = sr != 0 && !(lbr > best_t);
+            const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+            if (hl && hr) {
+                int nearc = left, farc = right;
+                if (tnr < tnl) { nearc = right; farc = left; }
+                stack_push(lds_col, ovf_col, ovf_stride, sp, farc);
+                ++sp;
+                cur = nearc;
+            } else if (hl) cur = left;
+            else if (hr) cur = right;
+            else if (sp == 0) cur = CUR_DONE;
+            else { --sp; cur = stack_pop(lds_col, ovf_col, ovf_stride, sp); }
         }
-        if (has_ray && cur < 0) {
-            // ProcessIntersectionForLeafNode (BVHTree.cpp:177-190): fresh result, array order, accept t>0 && t < best-0.001
-            const int leaf = ~cur;
-            const DevLeaf lf = sc.leaves[leaf];
-            Cand local;
-            local.t = FLT_MAX; local.prim = -1; local.ip = mk3(0, 0, 0); local.beta = local.gamma = 0;
-            for (int i = lf.start; i < lf.start + lf.count; ++i) {
-                const float4 q3 = prims4[i * 4 + 3], q0 = prims4[i * 4 + 0];
+        if (run_tri) {
+            if (do_tri) {
+                // ProcessIntersectionForLeafNode (BVHTree.cpp:177-190): fresh result per leaf, array order, accept t>0 && t < local-0.001
                 const int obj = __float_as_int(q3.x), kind = __float_as_int(q3.z);
                 if (obj != xf.id) enter_object<MOTION>(sc, obj, o, d, time, xf);
                 Cand c;
                 bool ok;
                 if (kind == DEV_PRIM_TRIANGLE) {
-                    const float4 q1 = prims4[i * 4 + 1], q2 = prims4[i * 4 + 2];
-                    if (COUNT) ++cnt_tris;
+                    if (COUNT) ++dbg.tris;
                     ok = hit_triangle<MOTION>(sc, q0, q1, q2, xf, o.x, d.x, time, eps, c);
                 } else {
-                    if (COUNT) ++cnt_sph;
+                    if (COUNT) ++dbg.sph;
                     ok = hit_sphere<MOTION>(sc, q0, xf, o.x, d.x, time, c);
                 }
-                if (ok && c.t > 0 && c.t < local.t - 0.001f) { local = c; local.prim = i; }
+                if (ok && c.t > 0 && c.t < local_t - 0.001f) {
+                    local_t = c.t; local_prim = prim_i;
+                    pay[0 * TRACE_BLOCK] = c.ip.x; pay[1 * TRACE_BLOCK] = c.ip.y; pay[2 * TRACE_BLOCK] = c.ip.z;
+                    pay[3 * TRACE_BLOCK] = c.beta; pay[4 * TRACE_BLOCK] = c.gamma;
+                }
+                if (++prim_i == prim_end) {
+                    // ProcessIntersectionForInternalNode (BVHTree.cpp:192-206) reduced over all leaves: smaller t wins, ties
+                    // go to the leaf that comes later in DFS order (Q4); the leaf's first record index is that order
+                    if (local_prim >= 0 && (local_t < best_t || (local_t == best_t && leaf_key > best_leaf))) {
+                        best_t = local_t; best_prim = local_prim; best_leaf = leaf_key;
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) pay[(5 + k) * TRACE_BLOCK] = pay[k * TRACE_BLOCK];
+                    }
+                    if (sp == 0) cur = CUR_DONE;
+                    else { --sp; cur = stack_pop(lds_col, ovf_col, ovf_stride, sp); }
+                }
             }
-            // ProcessIntersectionForInternalNode (BVHTree.cpp:192-206) reduced over all leaves: smaller t wins, ties go
-            // to the leaf that comes later in DFS order (Q4)
-            if (local.prim >= 0 && (local.t < best.t || (local.t == best.t && leaf > best_leaf))) { best = local; best_leaf = leaf; }
-            if (sp == 0) cur = CUR_DONE;
-            else { --sp; cur = (sp < LDS_STACK) ? lds_col[sp * TRACE_BLOCK] : ovf_col[(sp - LDS_STACK) * ovf_stride]; }
-        }
-
-        // ---------------- retire finished rays ----------------
-        if (has_ray && cur == CUR_DONE) {
-            if (COUNT && hist) { atomicAdd(&hist[io.kind(ray_idx) * 16 + (ray_steps ? 32 - __clz(ray_steps) : 0)], 1ull); ray_steps = 0; }
-            io.store(sc, ray_idx, best);
-            has_ray = false;
         }
     }
 }
@@ -495,17 +546,20 @@ struct BatchIO {
 };
 
 template <bool COUNT, bool MOTION, class IO>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_generic(DevScene sc, IO io, int n, const int *n_dev, int *fetch_counter, int *ovf, int ovf_stride, DevCounters *counters) {
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_trace_generic(DevScene sc, IO io, int n, const int *n_dev, int *fetch_counter, int *ovf, int ovf_stride, DevCounters *counters) {
     __shared__ int s_stack[LDS_STACK * TRACE_BLOCK];
+    __shared__ float s_pay[LDS_PAYLOAD * TRACE_BLOCK];
     if (n_dev) n += *n_dev;                       // + the part of the queue whose length was produced on the device
     const int gtid = blockIdx.x * TRACE_BLOCK + threadIdx.x;
-    unsigned cn = 0, cb = 0, ct = 0, cs = 0;
-    unsigned dbg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    trace_persistent<COUNT, MOTION, IO>(sc, io, n, fetch_counter, s_stack + threadIdx.x, ovf + gtid, ovf_stride, cn, cb, ct, cs, dbg, counters ? &counters->hist[0] : nullptr);
-    flush_counters<COUNT>(counters, cn, cb, ct, cs);
+    TraceDbg dbg;
+    dbg.nodes = dbg.boxes = dbg.tris = dbg.sph = 0;
+    for (int k = 0; k < 10; ++k) dbg.v[k] = 0;
+    trace_persistent<COUNT, MOTION, IO>(sc, io, n, fetch_counter, s_stack + threadIdx.x, s_pay + threadIdx.x, ovf + gtid, ovf_stride, dbg,
+                                        (COUNT && counters) ? &counters->hist[0] : nullptr);
+    flush_counters<COUNT>(counters, dbg.nodes, dbg.boxes, dbg.tris, dbg.sph);
     if (COUNT && counters) {
         for (int k = 0; k < 10; ++k) {
-            unsigned v = dbg[k];
+            unsigned v = dbg.v[k];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
             if ((threadIdx.x & 63) == 0) atomicAdd(&counters->dbg[IO::DBG_SET][k], (unsigned long long)v);
         }

@@ -69,7 +69,7 @@ struct DevCounters {        // accumulated with atomics when counting is enabled
     // 0 outer iterations x64, 1 lanes holding a ray, 2 refill rounds x64, 3 lanes refilled, 4 node steps x64, 5 lanes stepping,
     // 6 leaf primitive iterations x64, 7 lanes testing a primitive, 8 exact-slab fallback rounds x64, 9 lanes needing it
     unsigned long long dbg[2][10];   // [closest | shadow]
-    unsigned long long hist[32];      // rays by floor(log2(node steps))+1, [closest 16 | shadow 16]
+    unsigned long long hist[96];      // rays by floor(log2(node steps))+1, [closest 16 | shadow 16]; then ticks (100 MHz) and steps per bucket
 };
 
 void rt_launch_raygen(hipStream_t s, const DevCamera &cam, const int *pixel_list, int first_pixel, int n_samples, LevelBuf lv);

@@ -13,12 +13,12 @@ tris = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
 soup = synth.dragon_standin_scene(tris, 800, 480)
 ctx = rt.Context(0)
 ctx.upload(soup)
-if os.environ.get("RT_TRACE_DEBUG"):
-    ctx.render(0, want_ids=False, timing=2)        # counting frame: prints the lane-occupancy diagnostics
 streams = [int(x) for x in os.environ.get("RT_STREAMS", "0").split(",")]
 sizes = [tuple(int(v) for v in x.split("x")) for x in os.environ.get("RT_SIZES", "800x480").split(",")]
 for ns in streams:
   for (nx, ny) in sizes:
+    if os.environ.get("RT_TRACE_DEBUG"):
+        ctx.render(0, want_ids=False, timing=2, num_streams=ns, nx=nx, ny=ny)   # counting frame: prints the lane-occupancy diagnostics
     for _ in range(frames):
         hdr, _, _, st = ctx.render(0, want_ids=False, timing=1, num_streams=ns, nx=nx, ny=ny)
     print("size", nx, ny, "streams", ns, "rays", list(st.rays), "ms_total %.3f ms_kernels %.3f ms_trace(sum) %.3f busy %.3f launches %d" %
