@@ -132,7 +132,8 @@ struct rt_ctx {
     HostScene host;             // kept for rt_scene_bvh_info and as the owner of table sizes
     DevScene dev;               // device pointers
     // scene arenas
-    DevArray<DevNode> d_nodes;
+    DevArray<DevNode4> d_nodes;
+    DevArray<DevChain> d_chain;
     DevArray<DevLeaf> d_leaves;
     DevArray<DevPrim> d_prims;
     DevArray<DevObject> d_objects;
@@ -159,7 +160,7 @@ struct rt_ctx {
 };
 
 static void release_all(rt_ctx *c) {
-    c->d_nodes.release(); c->d_leaves.release(); c->d_prims.release(); c->d_objects.release(); c->d_verts.release(); c->d_tri_vert.release();
+    c->d_nodes.release(); c->d_chain.release(); c->d_leaves.release(); c->d_prims.release(); c->d_objects.release(); c->d_verts.release(); c->d_tri_vert.release();
     c->d_materials.release(); c->d_lights.release(); c->d_textures.release(); c->d_texels.release();
     for (auto &l : c->lanes) l.release();
     c->lanes.clear();
@@ -222,6 +223,7 @@ int rt_scene_upload(rt_ctx *c, const rt_scene_desc *scene) {
     for (const DevPrim &p : h.prims)
         if (p.kind == DEV_PRIM_SPHERE && !(h.objects[p.object].flags & DEV_OBJ_HAS_XFORM)) { c->error = "sphere object without a transform"; return RT_ERR_INVALID; }
     UPLOAD(c, c->d_nodes, h.nodes);
+    UPLOAD(c, c->d_chain, h.chain);
     UPLOAD(c, c->d_leaves, h.leaves);
     UPLOAD(c, c->d_prims, h.prims);
     UPLOAD(c, c->d_objects, h.objects);
@@ -233,10 +235,10 @@ int rt_scene_upload(rt_ctx *c, const rt_scene_desc *scene) {
     UPLOAD(c, c->d_texels, h.texels);
     DevScene &d = c->dev;
     d.p = h.params;
-    d.nodes = c->d_nodes.p; d.leaves = c->d_leaves.p; d.prims = c->d_prims.p; d.objects = c->d_objects.p; d.verts = c->d_verts.p;
+    d.nodes = c->d_nodes.p; d.chain = c->d_chain.p; d.leaves = c->d_leaves.p; d.prims = c->d_prims.p; d.objects = c->d_objects.p; d.verts = c->d_verts.p;
     d.tri_vert = c->d_tri_vert.p; d.materials = c->d_materials.p; d.lights = c->d_lights.p; d.textures = c->d_textures.p; d.texels = c->d_texels.p;
     // traversal stack overflow area: entries beyond the LDS part, one column per persistent thread
-    c->overflow_depth = std::max(0, h.params.bvh_depth + 2 - rt_trace_lds_stack_depth());
+    c->overflow_depth = std::max(0, h.params.stack_bound + 2 - rt_trace_lds_stack_depth());
     HIP_TRY(c, c->d_overflow.ensure((size_t)std::max(1, c->overflow_depth) * rt_trace_grid_threads()));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->has_scene = true;
@@ -365,6 +367,8 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
         if (d_pt) HIP_TRY(c, hipMemsetAsync(d_pt, 0, n_out * sizeof(float), s));
     }
 
+    if (const char *cap = getenv("RT_TRACE_BLOCK_CAP")) rt_set_trace_block_cap(atoi(cap));
+    if (const char *tml = getenv("RT_TRI_MIN_LANES")) c->dev.p.tri_min_lanes = atoi(tml);
     // streams
     int n_streams = opts->num_streams > 0 ? std::min<int>(opts->num_streams, RT_MAX_STREAMS) : RT_DEFAULT_STREAMS;
     int64_t batch_samples = opts->max_batch_samples > 0 ? opts->max_batch_samples : (4 << 20);

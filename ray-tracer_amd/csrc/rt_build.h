@@ -9,7 +9,8 @@
 
 struct HostScene {
     DevSceneParams params;
-    std::vector<DevNode> nodes;        // internal nodes, preorder
+    std::vector<DevNode4> nodes;       // 4-wide collapse of the reference tree, preorder
+    std::vector<DevChain> chain;       // one per reference node (index = reference node number, preorder of the build)
     std::vector<DevLeaf> leaves;       // DFS (left-to-right) order
     std::vector<DevPrim> prims;        // leaf order, duplicates inside one leaf removed
     std::vector<DevObject> objects;

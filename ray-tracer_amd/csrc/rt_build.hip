@@ -252,18 +252,18 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
     }
 
     // ---- flatten ------------------------------------------------------------------------------------
-    hs.nodes.clear(); hs.leaves.clear(); hs.prims.clear(); hs.ref_leaf_range.clear(); hs.leaf_boxes.clear();
+    hs.nodes.clear(); hs.chain.clear(); hs.leaves.clear(); hs.prims.clear(); hs.ref_leaf_range.clear(); hs.leaf_boxes.clear();
     hs.ref_prim_order.resize(nP);
     for (int64_t i = 0; i < nP; ++i) hs.ref_prim_order[i] = shapeRec[pshape[order[i]]].shape;
     std::memset(&hs.params, 0, sizeof(hs.params));
     hs.params.root = RT_NO_ROOT;
     auto store3 = [](float *dst, f3 v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; };
     if (!bn.empty()) {
-        // preorder numbering of internal nodes; DFS numbering of leaves
+        // DFS numbering of leaves (left to right); primitive records in that order
+        int wideDepth = 0;
         std::vector<int32_t> ref(bn.size(), 0);
         std::vector<int32_t> stack;
         stack.push_back(0);
-        std::vector<int32_t> internalOrder;
         while (!stack.empty()) {
             int32_t n = stack.back();
             stack.pop_back();
@@ -291,20 +291,68 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
                 const float bb[6] = {b.lo.x, b.lo.y, b.lo.z, b.hi.x, b.hi.y, b.hi.z};
                 hs.leaf_boxes.insert(hs.leaf_boxes.end(), bb, bb + 6);
             } else {
-                ref[n] = (int32_t)internalOrder.size();
-                internalOrder.push_back(n);
                 stack.push_back(bn[n].right);
                 stack.push_back(bn[n].left);
             }
         }
-        hs.nodes.resize(internalOrder.size());
-        for (size_t k = 0; k < internalOrder.size(); ++k) {
-            const BuildNode &b = bn[internalOrder[k]];
-            DevNode &dn = hs.nodes[k];
-            store3(dn.lmin, bn[b.left].box.lo); store3(dn.lmax, bn[b.left].box.hi);
-            store3(dn.rmin, bn[b.right].box.lo); store3(dn.rmax, bn[b.right].box.hi);
-            dn.left = ref[b.left]; dn.right = ref[b.right]; dn._pad[0] = dn._pad[1] = 0;
+        // one chain record per reference node
+        hs.chain.resize(bn.size());
+        for (size_t n = 0; n < bn.size(); ++n) {
+            DevChain &c = hs.chain[n];
+            store3(c.lo, bn[n].box.lo); store3(c.hi, bn[n].box.hi);
+            c._pad = 0;
+            if (n == 0) c.parent = -1;
+            if (bn[n].left >= 0) { hs.chain[bn[n].left].parent = (int32_t)n; hs.chain[bn[n].right].parent = (int32_t)n; }
         }
+        // 4-wide collapse: the children of a wide node are reference nodes; the internal child with the largest surface
+        // area is opened until four children are reached.  Wide nodes are numbered in preorder, siblings adjacent.
+        if (bn[0].left >= 0) {
+            struct WTask { int32_t bnode, windex, depth; };
+            std::vector<WTask> wwork;
+            hs.nodes.push_back(DevNode4());
+            wwork.push_back(WTask{0, 0, 1});
+            while (!wwork.empty()) {
+                const WTask tk = wwork.back();
+                wwork.pop_back();
+                wideDepth = std::max(wideDepth, tk.depth);
+                int32_t kids[4];
+                int nk = 2;
+                kids[0] = bn[tk.bnode].left; kids[1] = bn[tk.bnode].right;
+                while (nk < 4) {
+                    int pick = -1;
+                    float area = -1.0f;
+                    for (int i = 0; i < nk; ++i)
+                        if (bn[kids[i]].left >= 0) { const float a = surface_area(bn[kids[i]].box); if (a > area) { area = a; pick = i; } }
+                    if (pick < 0) break;
+                    const int32_t open = kids[pick];
+                    for (int i = nk; i > pick + 1; --i) kids[i] = kids[i - 1];      // keep left-to-right order
+                    kids[pick] = bn[open].left; kids[pick + 1] = bn[open].right;
+                    ++nk;
+                }
+                int32_t wref[4];
+                for (int i = nk - 1; i >= 0; --i) {        // allocate indices so that child 0's subtree follows first (preorder)
+                    if (bn[kids[i]].left < 0) wref[i] = ref[kids[i]];
+                    else { wref[i] = 0; }
+                }
+                for (int i = 0; i < nk; ++i)
+                    if (bn[kids[i]].left >= 0) { wref[i] = (int32_t)hs.nodes.size(); hs.nodes.push_back(DevNode4()); }
+                for (int i = nk - 1; i >= 0; --i)
+                    if (bn[kids[i]].left >= 0) wwork.push_back(WTask{kids[i], wref[i], tk.depth + 1});
+                DevNode4 &w = hs.nodes[tk.windex];
+                for (int i = 0; i < 4; ++i) {
+                    if (i < nk) {
+                        const Aabb &b = bn[kids[i]].box;
+                        w.minx[i] = b.lo.x; w.miny[i] = b.lo.y; w.minz[i] = b.lo.z; w.maxx[i] = b.hi.x; w.maxy[i] = b.hi.y; w.maxz[i] = b.hi.z;
+                        w.ref[i] = wref[i]; w.chain[i] = kids[i];
+                    } else {
+                        w.minx[i] = w.miny[i] = w.minz[i] = 0.0f; w.maxx[i] = w.maxy[i] = w.maxz[i] = 0.0f;
+                        w.ref[i] = DEV_REF_EMPTY; w.chain[i] = -1;
+                    }
+                }
+            }
+            ref[0] = 0;
+        }
+        hs.params.stack_bound = 3 * wideDepth + 2;     // a wide node pushes at most three children
         hs.params.root = ref[0];
         store3(hs.params.root_min, bn[0].box.lo); store3(hs.params.root_max, bn[0].box.hi);
     }
@@ -313,6 +361,7 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
     hs.params.bg_texture = d->bg_texture;
     hs.params.n_lights = d->n_lights; hs.params.n_materials = d->n_materials; hs.params.n_textures = d->n_textures;
     hs.params.bvh_depth = maxDepth;
+    hs.params.tri_min_lanes = 16;
     hs.params.has_motion = 0;
     for (const DevObject &o : hs.objects) if (o.flags & DEV_OBJ_MOTION) hs.params.has_motion = 1;
     float scale = 1.0f;

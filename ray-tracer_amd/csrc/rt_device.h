@@ -1,9 +1,13 @@
-// rt_device.h — HBM data layout shared by the host flattener (rt_build.cpp) and the gfx950 kernels.
+// rt_device.h — HBM data layout shared by the host flattener (rt_build.hip) and the gfx950 kernels.
 //
-// Everything the traversal touches is a 64-byte record (one 128-B HBM request carries two of them, one
-// L2 line exactly one):
-//   DevNode  — one per INTERNAL node; holds BOTH child boxes so one fetch decides both descents
-//   DevPrim  — one per leaf primitive reference, stored in leaf order (a leaf is a contiguous run)
+// The reference's binary BVH (same topology, same float boxes) is stored in two forms:
+//   DevNode4  — the traversal structure: the binary tree collapsed to 4-wide nodes (a node's children are reference
+//               nodes, opened greedily by surface area).  128 bytes, boxes as structure-of-arrays so that one lane
+//               tests the four child boxes with the same instruction stream.  Skipping the intermediate binary nodes is
+//               exact: boxes nest, and a leaf whose own box test is unambiguous provably passes every ancestor's test
+//               (DESIGN.md §4); only a leaf whose test is ambiguous walks DevChain[] with the reference's exact test.
+//   DevChain  — one record per reference node (box + parent), for that rare walk.
+//   DevPrim   — one per leaf primitive reference, stored in leaf order (a leaf is a contiguous run), 64 bytes.
 // Leaves are not nodes: a child reference < 0 is ~(count << 26 | start), the leaf's run inside DevPrim[] (count = 0: the
 // low bits are an index into DevLeaf[] instead, for leaves that do not fit).  DevPrim[] is stored in the reference
 // tree's left-to-right DFS leaf order, so `start` is also the tie-break key of Q4.
@@ -14,13 +18,21 @@
 
 #include "../../include/rt_mi355.h"
 
-struct alignas(64) DevNode {
-    float lmin[3], lmax[3];   // left child box   (BVHNode::bbox of left,  reference src/BVHTree.h:20)
-    float rmin[3], rmax[3];   // right child box
-    int32_t left, right;      // >= 0: internal node index, < 0: leaf reference (above)
-    int32_t _pad[2];
+#define DEV_REF_EMPTY 0x7fffffff  // unused child slot of a DevNode4
+struct alignas(128) DevNode4 {
+    float minx[4], miny[4], minz[4];   // child boxes (BVHNode::bbox of reference nodes, src/BVHTree.h:20)
+    float maxx[4], maxy[4], maxz[4];
+    int32_t ref[4];                    // >= 0: DevNode4 index, < 0: leaf reference, DEV_REF_EMPTY: no child
+    int32_t chain[4];                  // DevChain index (= reference node) of each child
 };
-static_assert(sizeof(DevNode) == 64, "DevNode must be 64 bytes");
+static_assert(sizeof(DevNode4) == 128, "DevNode4 must be 128 bytes");
+
+struct alignas(32) DevChain {
+    float lo[3], hi[3];                // the reference node's box
+    int32_t parent;                    // reference node above it, -1 for the root
+    int32_t _pad;
+};
+static_assert(sizeof(DevChain) == 32, "DevChain must be 32 bytes");
 
 #define DEV_LEAF_START_BITS 26
 #define DEV_LEAF_MAX_PACKED 31
@@ -68,10 +80,12 @@ struct DevSceneParams {
     float ambient[3];
     int32_t bg_texture;
     int32_t n_lights, n_materials, n_textures;
-    int32_t root;             // >= 0 internal node index, < 0 leaf reference, RT_NO_ROOT when the scene is empty
+    int32_t root;             // >= 0 DevNode4 index, < 0 leaf reference, RT_NO_ROOT when the scene is empty
     float root_min[3], root_max[3];
     float prune_err;          // absolute bound used to keep t-pruning conservative
-    int32_t bvh_depth;
+    int32_t bvh_depth;        // depth of the reference (binary) tree
+    int32_t stack_bound;      // most entries a traversal of the 4-wide tree can have on its stack
+    int32_t tri_min_lanes;    // run the primitive path of the traversal once this many lanes of a wave wait in a leaf
     int32_t has_motion;       // any object with a non-zero motion-blur vector (selects the kernel instantiation)
 };
 #define RT_NO_ROOT 0x7fffffff
@@ -79,7 +93,8 @@ struct DevSceneParams {
 // Pointers to the uploaded scene (all device memory).
 struct DevScene {
     DevSceneParams p;
-    const DevNode *nodes;
+    const DevNode4 *nodes;
+    const DevChain *chain;
     const DevLeaf *leaves;
     const DevPrim *prims;
     const DevObject *objects;

@@ -196,15 +196,17 @@ __device__ __noinline__ bool slab_exact(f3 bmin, f3 bmax, f3 o, f3 d) {
     return !(tf < tn);
 }
 
-// Fast form of the same test: multiplies by r = 1/d (computed once per ray with an IEEE division).  Every quotient is
-// within 2 ulp of the reference's, so the hit/miss decision is the reference's unless tn and tf are within ~1e-6
-// relative of each other; then (and for any NaN) the caller falls back to slab_exact.  Also returns the entry distance
-// (child ordering only) and a conservative lower bound `lb` on the x-only t of anything hit inside the box (pruning).
+// Fast form of the same test for one child box of a wide node: multiplies by r = 1/d (computed once per ray with an IEEE
+// division).  Every quotient is within 2 ulp of the reference's, so the hit/miss decision is the reference's unless tn and
+// tf are within ~1e-6 relative of each other; then (and for any NaN) the result is "undecided".  Also returns the entry
+// distance (child ordering only) and a conservative lower bound `lb` on the x-only t of anything hit inside the box.
 //   returns 0 = miss, 1 = hit, 2 = undecided
-__device__ __forceinline__ int slab_fast(f3 bmin, f3 bmax, f3 o, f3 r, f3 marg, float &tn_out, float &lb_out) {
-    const float ax = (bmin.x - o.x) * r.x, bx = (bmax.x - o.x) * r.x;
-    const float ay = (bmin.y - o.y) * r.y, by = (bmax.y - o.y) * r.y;
-    const float az = (bmin.z - o.z) * r.z, bz = (bmax.z - o.z) * r.z;
+//   amb = 1e-6 normally; +inf for a ray with a zero / denormal direction component (every test undecided, marg = +inf too)
+__device__ __forceinline__ int slab_fast(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, f3 o, f3 r, f3 marg,
+                                         float amb, float &tn_out, float &lb_out) {
+    const float ax = (bminx - o.x) * r.x, bx = (bmaxx - o.x) * r.x;
+    const float ay = (bminy - o.y) * r.y, by = (bmaxy - o.y) * r.y;
+    const float az = (bminz - o.z) * r.z, bz = (bmaxz - o.z) * r.z;
     const float nx = fminf(ax, bx), fx = fmaxf(ax, bx);
     const float ny = fminf(ay, by), fy = fmaxf(ay, by);
     const float nz = fminf(az, bz), fz = fmaxf(az, bz);
@@ -214,9 +216,28 @@ __device__ __forceinline__ int slab_fast(f3 bmin, f3 bmax, f3 o, f3 r, f3 marg, 
     lb = lb - fabsf(lb) * 2e-6f;
     tn_out = tn; lb_out = lb;
     const float diff = tf - tn;
-    const float thr = 1e-6f * (fabsf(tf) + fabsf(tn));
+    const float thr = amb * (fabsf(tf) + fabsf(tn));
     if (!(fabsf(diff) > thr)) return 2;
     return diff < 0.0f ? 0 : 1;
+}
+
+// Would the reference traversal reach the leaf whose reference node is `node`?  It does iff the exact box test passes
+// for the leaf's box and for every ancestor's (BVHTree.cpp:160-206).  Only called for leaves whose own fast test was
+// undecided (a ray grazing the leaf box within 1e-6 relative — every hit on a flat, axis-aligned leaf box is one — or a ray
+// with a zero direction component).  Walks up: an undecided box gets the exact test; the first box the fast test decides
+// ends the walk, because a decided hit implies that every box above it passes too (nesting).
+__device__ __noinline__ bool chain_visit(const DevChain *chain, int node, f3 o, f3 d, f3 r, float amb) {
+    const f3 zero = mk3(0, 0, 0);
+    while (node >= 0) {
+        const DevChain c = chain[node];
+        float tn, lb;
+        const int cls = slab_fast(c.lo[0], c.lo[1], c.lo[2], c.hi[0], c.hi[1], c.hi[2], o, r, zero, amb, tn, lb);
+        if (cls == 0) return false;
+        if (cls == 1) return true;
+        if (!slab_exact(ld3(c.lo), ld3(c.hi), o, d)) return false;
+        node = c.parent;
+    }
+    return true;
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -269,7 +290,8 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
     const float eps = sc.p.isect_eps;
     const bool no_scene = sc.p.root == RT_NO_ROOT;
 
-    bool has_ray = false, exact_only = false;
+    bool has_ray = false;
+    float amb = 1e-6f;
     int ray_idx = 0, sp = 0, cur = CUR_DONE, prim_i = 0, prim_end = 0;
     int best_prim = -1, best_leaf = -1, local_prim = -1, leaf_key = 0;
     float best_t = FLT_MAX, local_t = FLT_MAX;
@@ -329,10 +351,11 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                             bool alive = !no_scene && (d.x != 0.0f);
                             if (COUNT) ++dbg.boxes;
                             if (alive) alive = slab_exact(ld3(sc.p.root_min), ld3(sc.p.root_max), o, d);
+                            // a root that is itself a leaf was just decided exactly; below it every leaf is decided at its parent
                             if (alive) {
                                 r = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                                // a zero / denormal-range direction component: exact slab test everywhere (inf and NaN quotients)
-                                exact_only = !(fabsf(d.y) > 1e-30f && fabsf(d.z) > 1e-30f && fabsf(d.x) > 1e-30f);
+                                // a zero / denormal-range direction component (inf and NaN quotients): every fast test undecided
+                                amb = (fabsf(d.y) > 1e-30f && fabsf(d.z) > 1e-30f && fabsf(d.x) > 1e-30f) ? 1e-6f : __int_as_float(0x7f800000);
                                 const float err = sc.p.prune_err + 2e-4f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z));
                                 marg = mk3(err * fabsf(r.x) * 1.000001f, err * fabsf(r.y) * 1.000001f, err * fabsf(r.z) * 1.000001f);
                                 cur = sc.p.root;
@@ -364,33 +387,62 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
         const bool in_leaf = has_ray && cur == CUR_IN_LEAF;
         const bool at_node = has_ray && cur >= 0 && cur < CUR_IN_LEAF;
         const int n_leaf = __popcll(__ballot(in_leaf)), n_node = __popcll(__ballot(at_node));
-        const bool run_tri = n_leaf > 0 && (n_leaf >= TRI_MIN_LANES || n_leaf >= n_node);      // wave-uniform
+        const bool run_tri = n_leaf > 0 && (n_leaf >= sc.p.tri_min_lanes || n_leaf >= n_node);      // wave-uniform
         const bool do_tri = in_leaf && run_tri;
         // every lane loads (idle lanes re-read record 0 of the node array): no merge of loaded and stale registers
-        const float4 *rec = do_tri ? prims4 + 4 * (size_t)prim_i : nodes4 + (at_node ? 4 * (size_t)cur : 0);
+        const float4 *rec = do_tri ? prims4 + 4 * (size_t)prim_i : nodes4 + (at_node ? 8 * (size_t)cur : 0);
         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
         if (COUNT) { ++dbg.v[4]; if (at_node) ++dbg.v[5]; if (do_tri) ++dbg.v[7]; if (run_tri) ++dbg.v[6]; }
         if (at_node) {
-            float tnl, tnr, lbl, lbr;
-            int sl = slab_fast(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, r, marg, tnl, lbl);
-            int sr = slab_fast(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, r, marg, tnr, lbr);
-            if (exact_only) { sl = 2; sr = 2; lbl = lbr = -FLT_MAX; }
-            if (COUNT) { if (sl == 2 || sr == 2) ++dbg.v[9]; if (__any(sl == 2 || sr == 2)) ++dbg.v[8]; }
-            if (sl == 2) sl = slab_exact(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, d) ? 1 : 0;
-            if (sr == 2) sr = slab_exact(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, d) ? 1 : 0;
-            if (COUNT) { ++dbg.nodes; dbg.boxes += 2; ++ray_steps; }
-            const bool hl = sl != 0 && !(lbl > best_t);
-            const bool hr = sr != 0 && !(lbr > best_t);
-            const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
-            if (hl && hr) {
-                int nearc = left, farc = right;
-                if (tnr < tnl) { nearc = right; farc = left; }
-                stack_push(lds_col, ovf_col, ovf_stride, sp, farc);
-                ++sp;
-                cur = nearc;
-            } else if (hl) cur = left;
-            else if (hr) cur = right;
-            else if (sp == 0) cur = CUR_DONE;
+            // four child boxes (structure of arrays: q0..q2 = min x,y,z of the four children, q3..q5 = max), q6 = references
+            const float4 q4 = rec[4], q5 = rec[5], q6 = rec[6];
+            const float mnx[4] = {q0.x, q0.y, q0.z, q0.w}, mny[4] = {q1.x, q1.y, q1.z, q1.w}, mnz[4] = {q2.x, q2.y, q2.z, q2.w};
+            const float mxx[4] = {q3.x, q3.y, q3.z, q3.w}, mxy[4] = {q4.x, q4.y, q4.z, q4.w}, mxz[4] = {q5.x, q5.y, q5.z, q5.w};
+            int cref[4] = {__float_as_int(q6.x), __float_as_int(q6.y), __float_as_int(q6.z), __float_as_int(q6.w)};
+            float key[4];
+            bool need_chain = false;
+            int cls[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float tn, lb;
+                int c = slab_fast(mnx[i], mny[i], mnz[i], mxx[i], mxy[i], mxz[i], o, r, marg, amb, tn, lb);
+                if (c == 2) lb = -FLT_MAX;                        // undecided: no pruning either
+                if (cref[i] == DEV_REF_EMPTY || lb > best_t) c = 0;
+                // an undecided INTERNAL child is entered (boxes nest: that is conservative); an undecided LEAF is decided exactly
+                if (c == 2) { if (cref[i] < 0) need_chain = true; else c = 1; }
+                cls[i] = c;
+                key[i] = fminf(fmaxf(tn, 0.0f), FLT_MAX);         // NaN -> 0
+            }
+            if (COUNT) { ++dbg.nodes; dbg.boxes += 4; ++ray_steps; if (need_chain) ++dbg.v[9]; if (__any(need_chain)) ++dbg.v[8]; }
+            if (need_chain) {
+                const float4 q7 = rec[7];
+                const int cch[4] = {__float_as_int(q7.x), __float_as_int(q7.y), __float_as_int(q7.z), __float_as_int(q7.w)};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (cls[i] == 2) cls[i] = chain_visit(sc.chain, cch[i], o, d, r, amb) ? 1 : 0;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (cls[i] == 0) key[i] = __int_as_float(0x7f800000);      // +inf: not taken, sorts last
+            // sorting network on (entry distance, reference): nearest first
+#define CSWAP(a, b) { const bool sw = key[b] < key[a]; const float ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b]; \
+                      const int ra = sw ? cref[b] : cref[a], rb = sw ? cref[a] : cref[b]; key[a] = ka; key[b] = kb; cref[a] = ra; cref[b] = rb; }
+            CSWAP(0, 1) CSWAP(2, 3) CSWAP(0, 2) CSWAP(1, 3) CSWAP(1, 2)
+#undef CSWAP
+            const float inf = __int_as_float(0x7f800000);
+            if (key[0] < inf) {
+                const int npush = (key[1] < inf ? 1 : 0) + (key[2] < inf ? 1 : 0) + (key[3] < inf ? 1 : 0);
+                if (sp + 3 <= LDS_STACK) {
+                    // branch-free: the taken children go to sp .. sp+npush-1 (farthest lowest), the others to a scratch row
+                    const int i1 = npush >= 1 ? sp + npush - 1 : LDS_STACK, i2 = npush >= 2 ? sp + npush - 2 : LDS_STACK, i3 = npush >= 3 ? sp : LDS_STACK;
+                    lds_col[i1 * TRACE_BLOCK] = cref[1]; lds_col[i2 * TRACE_BLOCK] = cref[2]; lds_col[i3 * TRACE_BLOCK] = cref[3];
+                } else {
+                    if (npush >= 3) stack_push(lds_col, ovf_col, ovf_stride, sp, cref[3]);
+                    if (npush >= 2) stack_push(lds_col, ovf_col, ovf_stride, sp + npush - 2, cref[2]);
+                    if (npush >= 1) stack_push(lds_col, ovf_col, ovf_stride, sp + npush - 1, cref[1]);
+                }
+                sp += npush;
+                cur = cref[0];
+            } else if (sp == 0) cur = CUR_DONE;
             else { --sp; cur = stack_pop(lds_col, ovf_col, ovf_stride, sp); }
         }
         if (run_tri) {
@@ -547,7 +599,7 @@ struct BatchIO {
 
 template <bool COUNT, bool MOTION, class IO>
 __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_trace_generic(DevScene sc, IO io, int n, const int *n_dev, int *fetch_counter, int *ovf, int ovf_stride, DevCounters *counters) {
-    __shared__ int s_stack[LDS_STACK * TRACE_BLOCK];
+    __shared__ int s_stack[(LDS_STACK + 1) * TRACE_BLOCK];      // + one scratch row for the branch-free push
     __shared__ float s_pay[LDS_PAYLOAD * TRACE_BLOCK];
     if (n_dev) n += *n_dev;                       // + the part of the queue whose length was produced on the device
     const int gtid = blockIdx.x * TRACE_BLOCK + threadIdx.x;
@@ -582,9 +634,12 @@ __global__ __launch_bounds__(256) void k_finalize_batch(DevScene sc, const rt_ra
     hits[i] = out;
 }
 
+static int g_trace_block_cap = 0;
+void rt_set_trace_block_cap(int cap) { g_trace_block_cap = cap; }
 static int trace_blocks(int n) {
     int want = (n + TRACE_BLOCK - 1) / TRACE_BLOCK;
     int cap = NUM_CUS * TRACE_BLOCKS_PER_CU;
+    if (g_trace_block_cap > 0 && g_trace_block_cap < cap) cap = g_trace_block_cap;
     return want < cap ? (want < 1 ? 1 : want) : cap;
 }
 template <class IO>

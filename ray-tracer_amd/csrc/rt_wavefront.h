@@ -84,6 +84,7 @@ void rt_launch_shade_post(hipStream_t s, const DevScene &sc, const DevCamera &ca
 void rt_launch_backward(hipStream_t s, LevelBuf lv, int n, LevelBuf next, int has_next);
 void rt_launch_resolve(hipStream_t s, const DevCamera &cam, const int *pixel_list, int first_pixel, int n_pixels, LevelBuf lv0, int compact,
                        float *hdr, int *prim_id, float *prim_t);
+void rt_set_trace_block_cap(int cap);   // experiment hook: upper bound of the persistent grid (0 = default)
 int rt_trace_grid_threads();     // number of persistent threads the trace kernels are launched with
 int rt_trace_lds_stack_depth();  // stack entries kept in LDS per lane
 
