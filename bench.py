@@ -26,9 +26,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-RAY_BYTES = 48                 # ray record read per query: origin+time, direction+medium, meta (3 x 16 B)
-HIT_BYTES = 64                 # hit record written per closest-hit query (4 x 16 B); a shadow query writes 4 B
-NODE_BYTES = 64                # one DevNode (both child boxes) per internal-node visit
+RAY_BYTES = 32                 # closest-hit query: origin+time, direction+medium read (2 x 16 B)
+HIT_BYTES = 32                 # closest-hit query: raw hit record written (2 x 16 B)
+SHADOW_BYTES = 52              # shadow query: origin, direction+distance, shaded point+slot read (3 x 16 B), 4 B result written
+NODE_BYTES = 112               # node step: the 7 x 16 B of a DevNode4 the step reads (four child boxes + references)
 PRIM_BYTES = 64                # one DevPrim record per triangle / sphere test
 RES_BY_GPUS = {1: (800, 480), 2: (1600, 480), 4: (1600, 960), 8: (3200, 960)}
 TILE = 32
@@ -127,11 +128,11 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     value = total_rays / (elapsed / args.steps) / 1e6
 
-    # roofline of the dominant kernels (k_trace + k_trace_shadow), rank 0's launches: algorithmic bytes / HIP-event time
+    # roofline of the dominant kernel (k_trace_generic), rank 0's launches: algorithmic bytes / HIP-event time
     n_node, n_tri, n_sph = float(st_count.node_visits), float(st_count.tri_tests), float(st_count.sphere_tests)
     n_rays = float(sum(st_count.rays))
     n_shadow = float(st_count.rays[abi.RT_RAY_SHADOW])
-    frame_bytes = NODE_BYTES * n_node + PRIM_BYTES * (n_tri + n_sph) + RAY_BYTES * n_rays + HIT_BYTES * (n_rays - n_shadow) + 4 * n_shadow
+    frame_bytes = NODE_BYTES * n_node + PRIM_BYTES * (n_tri + n_sph) + (RAY_BYTES + HIT_BYTES) * (n_rays - n_shadow) + SHADOW_BYTES * n_shadow
     launches = sum(s.trace_launches for s in st_steps) / args.steps
     trace_ms = sum(s.ms_trace for s in st_steps) / args.steps
     bytes_per_launch = frame_bytes / launches
@@ -145,7 +146,7 @@ def main():
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic, "kernel": "k_trace+k_trace_shadow", "launches_per_frame": launches,
+                "traffic": traffic, "kernel": "k_trace_generic (closest-hit rays of a level + shadow rays of the level before, one launch)", "launches_per_frame": launches,
                 "avg_launch_ms": round(avg_launch_ms, 5), "algorithmic_bytes_per_launch": round(bytes_per_launch),
                 "per_ray": {"nodes": round(n_node / n_rays, 2), "tris": round(n_tri / n_rays, 2), "bytes": round(frame_bytes / n_rays, 1)},
                 "trace_ms_per_frame": round(trace_ms, 4)}

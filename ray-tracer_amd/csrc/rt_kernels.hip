@@ -485,25 +485,32 @@ struct HitOut {
     f3 ip, n; float u, v, theta, phi;
 };
 
+// inverse(transpose(M)) of a moving object at ray time (kept out of line; static objects read DevObject::inv directly)
+__device__ __noinline__ void motion_inverse(const DevObject &ob, float time, float *inv, int *flags) {
+    float M[16];
+    object_matrices(ob, time, M, inv, *flags);
+}
+
 // What Triangle::Intersect / Sphere::Intersect put into the SurfaceIntersection of the winning primitive.
-__device__ __noinline__ void finalize_hit(const DevScene &sc, f3 o, f3 d, float time, const Cand &best, HitOut &h) {
+__device__ __forceinline__ void finalize_hit(const DevScene &sc, f3 o, f3 d, float time, const Cand &best, HitOut &h) {
     h.t = best.t; h.prim = best.prim; h.ip = best.ip; h.theta = h.phi = 0; h.u = h.v = 0; h.n = mk3(0, 0, 0);
     if (best.prim < 0) { h.shape = -1; h.object = -1; h.t = FLT_MAX; return; }
     const DevPrim &P = sc.prims[best.prim];
     const DevObject &ob = sc.objects[P.object];
     h.shape = P.shape; h.object = P.object;
-    float M[16], inv[16];
+    float inv_m[16];
+    const float *inv = ob.inv;
     int flags = ob.flags | ((ob.flags & DEV_OBJ_HAS_XFORM) ? 0 : DEV_OBJ_IDENTITY);
-    if (ob.flags & DEV_OBJ_HAS_XFORM) object_matrices(ob, time, M, inv, flags);
+    if ((ob.flags & DEV_OBJ_HAS_XFORM) && (ob.flags & DEV_OBJ_MOTION)) { motion_inverse(ob, time, inv_m, &flags); inv = inv_m; }
     if (P.kind == DEV_PRIM_TRIANGLE) {
         const float eps = sc.p.isect_eps;
-        const int *tv = sc.tri_vert + 3 * (size_t)P.shape;
-        const DevVertex &a = sc.verts[tv[0]], &b = sc.verts[tv[1]], &c = sc.verts[tv[2]];
         const float e = 1 + eps;
         const float w0 = e - best.beta - best.gamma;                           // Triangle.cpp:252-266
+        f3 n = ld3(P.nrm);
+        const int *tv = sc.tri_vert + 3 * (size_t)P.shape;
+        const DevVertex &a = sc.verts[tv[0]], &b = sc.verts[tv[1]], &c = sc.verts[tv[2]];
         h.u = a.uv[0] * w0 + b.uv[0] * best.beta + c.uv[0] * best.gamma;
         h.v = a.uv[1] * w0 + b.uv[1] * best.beta + c.uv[1] * best.gamma;
-        f3 n = ld3(P.nrm);
         if (ob.flags & DEV_OBJ_SMOOTH) n = normalize3(ld3(a.n) * w0 + ld3(b.n) * best.beta + ld3(c.n) * best.gamma);
         if (!(flags & DEV_OBJ_IDENTITY)) n = normalize3(mat_mul_xyz(inv, n.x, n.y, n.z, 0.0f));   // Triangle.cpp:299-300
         h.n = n;
@@ -889,14 +896,15 @@ __device__ __noinline__ f3 tweak_normal(const DevScene &sc, const Surf &s, int t
 // ====================================================================================================
 // Lights and BRDFs (Q16, Q17)
 // ====================================================================================================
-__device__ void light_vars(const rt_light &L, int li, f3 ip, unsigned seed, const int4 meta, f3 &to_light, float &dist) {   // Light.cpp:89-129
+template <bool RNG>
+__device__ __forceinline__ void light_vars(const rt_light &L, int li, f3 ip, unsigned seed, const int4 meta, f3 &to_light, float &dist) {   // Light.cpp:89-129
     if (L.type == RT_LIGHT_DIRECTIONAL) {
         dist = 1e9;
         to_light = normalize3(-ld3(L.direction));
         return;
     }
     f3 pos = ld3(L.position);
-    if (L.type == RT_LIGHT_AREA) {
+    if (RNG && L.type == RT_LIGHT_AREA) {
         double u[4];
         rng_slot(seed, (unsigned)meta.x, (unsigned)meta.y, (unsigned)meta.z, SLOT_LIGHT0 + li, u);
         double p1 = uni(u[0], 0.0f, 1.0f), p2 = uni(u[1], 0.0f, 1.0f);
@@ -993,6 +1001,9 @@ __device__ __forceinline__ bool replaces_all(const DevScene &sc, const DevObject
 // shadow ray per light into the compact shadow queue, and spawn the reflection / refraction children into level depth+1
 // (RecursiveComputation.cpp) together with the coefficients the backward sweep folds them with.  Nothing here needs the
 // shadow results, so the children of this level and the shadow rays of this level are traced by ONE launch.
+// NTEX: the scene has normal textures; RNG: it has area lights or glossy materials (the only consumers of random numbers
+// here).  The plain instantiation carries neither code path (and not their registers: 2x the occupancy).
+template <bool NTEX, bool RNG>
 __global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, LevelBuf lv, int n, ShadowBuf sb, LevelBuf next, int depth,
                                                    int *next_count) {
     // Queue space is reserved once per 256-thread block (two atomics per block: same-address atomics from every wave cost
@@ -1027,7 +1038,7 @@ __global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, L
         mat_index = ob.material;
         if (replaces_all(sc, ob)) lit = false;                         // LightContributionCalculator.cpp:54-55
         else {
-            if (ob.tex_normal >= 0) s.n = tweak_normal(sc, s, ob.tex_normal);
+            if (NTEX && ob.tex_normal >= 0) s.n = tweak_normal(sc, s, ob.tex_normal);
             recurse = true;
             if (internal) lit = false;
         }
@@ -1091,7 +1102,7 @@ __global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, L
             // reflection ray (:62-122)
             const f3 to_viewer2 = normalize3(o - s.ip);
             f3 vrd = normalize3(N * 2.0f * dot3(to_viewer2, N) - to_viewer2);
-            if (m.type != RT_MAT_DIELECTRIC && m.roughness > 0) {   // glossy tilt (Q15); the dielectric path does not call it
+            if (RNG && m.type != RT_MAT_DIELECTRIC && m.roughness > 0) {   // glossy tilt (Q15); the dielectric path does not call it
                 const int mi = fabsf(vrd.x) < fabsf(vrd.y) ? (fabsf(vrd.x) < fabsf(vrd.z) ? 0 : 2) : (fabsf(vrd.y) < fabsf(vrd.z) ? 1 : 2);
                 f3 rp = vrd;
                 if (mi == 0) rp.x = 1.0f; else if (mi == 1) rp.y = 1.0f; else rp.z = 1.0f;
@@ -1145,7 +1156,7 @@ __global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, L
         if (!lit) { sb.occluded[k] = 0; continue; }
         const int q = s_base[0] + l * block_lit + lit_rank;
         f3 to_light; float dist;
-        light_vars(sc.lights[l], l, s.ip, cam.seed, meta, to_light, dist);
+        light_vars<RNG>(sc.lights[l], l, s.ip, cam.seed, meta, to_light, dist);
         const f3 so = s.ip + s.n * sc.p.shadow_eps;                    // LightContributionCalculator.cpp:133
         sb.ldir[k] = make_float4(to_light.x, to_light.y, to_light.z, dist);
         sb.o[q] = make_float4(so.x, so.y, so.z, time);
@@ -1175,14 +1186,16 @@ __global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, L
 // the children this level spawned, from the child table (block reduction, one atomic per block and kind).
 __global__ __launch_bounds__(256) void k_count_kinds(LevelBuf lv, int n, const int *shadow_count, unsigned long long *kind_counts) {
     __shared__ unsigned s_r[4], s_t[4];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int2 ch = make_int2(-1, -1);
-    if (i < n) ch = lv.child[i];
-    const unsigned long long mr = __ballot(ch.x >= 0), ml = __ballot(ch.y >= 0);
-    if ((threadIdx.x & 63) == 0) { s_t[threadIdx.x >> 6] = __popcll(mr); s_r[threadIdx.x >> 6] = __popcll(ml); }
+    unsigned r = 0, t = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int2 ch = lv.child[i];
+        t += ch.x >= 0 ? 1u : 0u; r += ch.y >= 0 ? 1u : 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) { r += __shfl_down(r, off); t += __shfl_down(t, off); }
+    if ((threadIdx.x & 63) == 0) { s_t[threadIdx.x >> 6] = t; s_r[threadIdx.x >> 6] = r; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned t = s_t[0] + s_t[1] + s_t[2] + s_t[3], r = s_r[0] + s_r[1] + s_r[2] + s_r[3];
+        t = s_t[0] + s_t[1] + s_t[2] + s_t[3]; r = s_r[0] + s_r[1] + s_r[2] + s_r[3];
         if (r) atomicAdd(&kind_counts[RT_RAY_REFLECT], (unsigned long long)r);
         if (t) atomicAdd(&kind_counts[RT_RAY_REFRACT], (unsigned long long)t);
         if (blockIdx.x == 0 && shadow_count) atomicAdd(&kind_counts[RT_RAY_SHADOW], (unsigned long long)*shadow_count);
@@ -1191,8 +1204,13 @@ __global__ __launch_bounds__(256) void k_count_kinds(LevelBuf lv, int n, const i
 void rt_launch_shade_pre(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, ShadowBuf sb, LevelBuf next, int depth,
                          int *next_count, unsigned long long *kind_counts) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_shade_pre, dim3((n + 255) / 256), dim3(256), 0, s, sc, cam, lv, n, sb, next, depth, next_count);
-    if (kind_counts) hipLaunchKernelGGL(k_count_kinds, dim3((n + 255) / 256), dim3(256), 0, s, lv, n, sb.count, kind_counts);
+    const dim3 g((n + 255) / 256), b(256);
+    const bool ntex = sc.p.has_normal_tex != 0, rng = sc.p.has_rng != 0;
+    if (ntex && rng) hipLaunchKernelGGL((k_shade_pre<true, true>), g, b, 0, s, sc, cam, lv, n, sb, next, depth, next_count);
+    else if (ntex) hipLaunchKernelGGL((k_shade_pre<true, false>), g, b, 0, s, sc, cam, lv, n, sb, next, depth, next_count);
+    else if (rng) hipLaunchKernelGGL((k_shade_pre<false, true>), g, b, 0, s, sc, cam, lv, n, sb, next, depth, next_count);
+    else hipLaunchKernelGGL((k_shade_pre<false, false>), g, b, 0, s, sc, cam, lv, n, sb, next, depth, next_count);
+    if (kind_counts) hipLaunchKernelGGL(k_count_kinds, dim3(std::min((n + 255) / 256, 512)), dim3(256), 0, s, lv, n, sb.count, kind_counts);
 }
 
 // After the shadow rays of the level are traced: the local colour of every hit (ProcessLights, LightContributionCalculator.cpp:98-124),
