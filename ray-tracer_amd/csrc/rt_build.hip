@@ -362,6 +362,7 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
     hs.params.n_lights = d->n_lights; hs.params.n_materials = d->n_materials; hs.params.n_textures = d->n_textures;
     hs.params.bvh_depth = maxDepth;
     hs.params.tri_min_lanes = 16;
+    hs.params.donate = 1;
     hs.params.has_normal_tex = 0; hs.params.has_rng = 0;
     for (const DevObject &o : hs.objects) if (o.tex_normal >= 0) hs.params.has_normal_tex = 1;
     for (const rt_light &l : hs.lights) if (l.type == RT_LIGHT_AREA) hs.params.has_rng = 1;

@@ -20,7 +20,7 @@
 #include "rt_wavefront.h"
 
 #define TRACE_BLOCK 256
-#define LDS_STACK 24
+#define LDS_STACK 20
 #define TRACE_BLOCKS_PER_CU 6
 #define NUM_CUS 256
 
@@ -261,10 +261,17 @@ __device__ __noinline__ bool chain_visit(const DevChain *chain, int node, f3 o, 
 // ----------------------------------------------------------------------------------------------------
 #define CUR_DONE 0x7ffffffe      // lane finished its ray (stack empty), result not yet stored
 #define CUR_IN_LEAF 0x7ffffffd   // lane is walking the primitive run [prim_i, prim_end) of a leaf
+#define CUR_WAIT 0x7ffffffc      // lane finished its own traversal and waits for parts it gave away
 #define TRACE_CHUNK 64           // rays a wave reserves per atomic
 #define REFILL_MIN_IDLE 8        // retire + refill once this many lanes are idle
 #define TRI_MIN_LANES 16         // run the primitive path once this many lanes wait in a leaf
-#define LDS_PAYLOAD 10           // floats per lane: ip.xyz, beta, gamma of the leaf-local candidate, then of the best one
+#define LDS_PAYLOAD 15           // dwords per lane: ip.xyz, beta, gamma of the leaf-local candidate, then of the best one, then the
+                                 // rarely used lane state below
+#define PAY_RAY_IDX 10           // index of the ray in the queue
+#define PAY_PARENT 11            // lane this part of a ray reports to (-1: it owns the ray)
+#define PAY_PENDING 12           // parts given away and not yet merged
+#define PAY_DY 13                // direction y, z (the hot path only needs 1/d and d.x)
+#define PAY_DZ 14
 
 struct TraceDbg { unsigned nodes, boxes, tris, sph, v[10]; };
 
@@ -292,27 +299,63 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
 
     bool has_ray = false;
     float amb = 1e-6f;
-    int ray_idx = 0, sp = 0, cur = CUR_DONE, prim_i = 0, prim_end = 0;
-    int best_prim = -1, best_leaf = -1, local_prim = -1, leaf_key = 0;
+    int sp = 0, cur = CUR_DONE, prim_i = 0, prim_end = 0;
+    int *payi = reinterpret_cast<int *>(pay);
+    int best_prim = -1, local_prim = -1, leaf_key = 0;
     float best_t = FLT_MAX, local_t = FLT_MAX;
-    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), r = mk3(0, 0, 1), marg = mk3(0, 0, 0);
+    f3 o = mk3(0, 0, 0), r = mk3(0, 0, 1), marg = mk3(0, 0, 0);
+    float dirx = 0;                  // d.x (Q2: every hit parameter divides by it); d.y, d.z live in LDS
     float time = 0;
     ObjXf xf;
-    xf.id = -2; xf.flags = 0; xf.o = o; xf.d = d;
+    xf.id = -2; xf.flags = 0; xf.o = o; xf.d = o;
     unsigned ray_steps = 0;
     unsigned long long ray_t0 = 0;
     bool exhausted = false;          // wave-uniform: the global queue has no more chunks
     int chunk_next = 0, chunk_end = 0;
+    // work donation (see the retire block): a lane may hand the bottom entry of its stack to an idle lane of the wave
+    int sbase = 0;                   // the stack is [sbase, sp): entries below sbase were given away
+    int plane = lane;                // lane this part of a ray reports to (its own lane: it owns the ray)
+    float bound = FLT_MAX;           // pruning bound: min over this lane's best_t and its parent's bound
+    bool any_parts = false;          // wave-uniform: some lane works on a donated part
 
     for (;;) {
         if (COUNT) { ++dbg.v[0]; if (has_ray && cur != CUR_DONE) ++dbg.v[1]; }
         // ---------------- retire finished rays, refill idle lanes (batched) ----------------
+        // When the queue is exhausted the wave would run on with a few long rays and mostly idle lanes (config 2: 2-6 rays per
+        // lane and launch, so this phase is a large part of every launch).  Then lanes that still have stack entries DONATE
+        // the bottom one (the largest pending subtree) to idle lanes: the part is traversed like a ray of its own, prunes
+        // with its parent's current bound, and is merged back by the (t, leaf order) rule, which does not depend on the
+        // order of visits.  A lane finishes its ray only when all parts it gave away have been merged.
         {
-            const bool done = has_ray && cur == CUR_DONE;
-            const unsigned long long idle = __ballot(!has_ray || done);
-            const int nidle = __popcll(idle);
-            if (nidle >= REFILL_MIN_IDLE) {
-                if (done) {
+            if (any_parts && has_ray && cur == CUR_DONE && payi[PAY_PENDING * TRACE_BLOCK] > 0) cur = CUR_WAIT;     // retire only after the merges
+            const bool working = has_ray && cur != CUR_DONE && cur != CUR_WAIT;
+            bool fin = has_ray && cur == CUR_DONE;
+            const unsigned long long idle0 = __ballot(!has_ray || fin);
+            unsigned long long parts_done = any_parts ? __ballot(fin && plane != lane) : 0ull;
+            if (__popcll(idle0) >= REFILL_MIN_IDLE || parts_done || !__any(working)) {
+                // 1. merge finished parts into the lanes they report to
+                while (parts_done) {
+                    const int s = __ffsll((long long)parts_done) - 1;
+                    parts_done &= parts_done - 1;
+                    const int p = __shfl(plane, s), bp = __shfl(best_prim, s);
+                    const float bt = __shfl(best_t, s);
+                    if (lane == p) {
+                        // records are stored in leaf order: a larger record index is a later leaf (parts cover disjoint leaves)
+                        if (bp >= 0 && (bt < best_t || (bt == best_t && bp > best_prim))) {
+                            best_t = bt; best_prim = bp;
+#pragma unroll
+                            for (int k = 5; k < 10; ++k) pay[k * TRACE_BLOCK] = pay[k * TRACE_BLOCK + (s - lane)];
+                        }
+                        const int left = payi[PAY_PENDING * TRACE_BLOCK] - 1;
+                        payi[PAY_PENDING * TRACE_BLOCK] = left;
+                        if (left == 0 && cur == CUR_WAIT) cur = CUR_DONE;
+                    }
+                    if (lane == s) { has_ray = false; plane = lane; }
+                }
+                // 2. retire finished rays
+                fin = has_ray && cur == CUR_DONE && plane == lane;
+                if (fin) {
+                    const int ray_idx = payi[PAY_RAY_IDX * TRACE_BLOCK];
                     if (COUNT && hist) {
                         const int bk = io.kind(ray_idx) * 16 + (ray_steps ? 32 - __clz(ray_steps) : 0);
                         atomicAdd(&hist[bk], 1ull);
@@ -329,7 +372,10 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                     io.store(sc, ray_idx, best);
                     has_ray = false;
                 }
-                if (!exhausted || chunk_next < chunk_end) {
+                const unsigned long long idle = __ballot(!has_ray);
+                const int nidle = __popcll(idle);
+                if (nidle >= REFILL_MIN_IDLE && (!exhausted || chunk_next < chunk_end)) {
+                    // 3a. new rays from the wave's chunk of the queue
                     if (chunk_next >= chunk_end) {
                         int base = 0;
                         if (lane == 0) base = atomicAdd(fetch_counter, TRACE_CHUNK);
@@ -343,10 +389,14 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                     if (COUNT) { ++dbg.v[2]; if (!has_ray && rank < avail) ++dbg.v[3]; }
                     if (!has_ray && rank < avail) {
                         const int mine = chunk_next + rank;
+                        f3 d;
                         if (io.load(mine, o, d, time)) {
-                            ray_idx = mine;
+                            payi[PAY_RAY_IDX * TRACE_BLOCK] = mine; payi[PAY_PENDING * TRACE_BLOCK] = 0;
+                            pay[PAY_DY * TRACE_BLOCK] = d.y; pay[PAY_DZ * TRACE_BLOCK] = d.z;
+                            dirx = d.x;
                             if (COUNT) ray_t0 = wall_clock64();
-                            best_t = FLT_MAX; best_prim = -1; best_leaf = -1; sp = 0; xf.id = -2; prim_i = prim_end = 0;
+                            best_t = FLT_MAX; best_prim = -1; sp = sbase = 0; xf.id = -2; prim_i = prim_end = 0;
+                            plane = lane; bound = FLT_MAX;
                             // Q2: the hit parameter is (ip.x - o.x)/d.x; with d.x == 0 (or NaN) no hit is ever accepted.
                             bool alive = !no_scene && (d.x != 0.0f);
                             if (COUNT) ++dbg.boxes;
@@ -368,10 +418,55 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                         }
                     }
                     chunk_next += nidle < avail ? nidle : avail;
+                } else if (nidle >= REFILL_MIN_IDLE && sc.p.donate) {
+                    // 3b. nothing left in the queue: split the rays still in flight
+                    const bool can_give = has_ray && cur != CUR_DONE && sp > sbase;
+                    const unsigned long long givers = __ballot(can_give);
+                    const int ngive = __popcll(givers);
+                    const int np = nidle < ngive ? nidle : ngive;
+                    if (np > 0) {
+                        int entry = 0;
+                        if (can_give && __popcll(givers & lt_mask) < np) {
+                            entry = stack_pop(lds_col, ovf_col, ovf_stride, sbase);
+                            ++sbase;
+                            payi[PAY_PENDING * TRACE_BLOCK] += 1;
+                        }
+                        const int irank = __popcll(idle & lt_mask);
+                        const bool take = !has_ray && irank < np;
+                        int src = lane;
+                        if (take) {                                   // the irank-th giver
+                            unsigned long long m = givers;
+                            for (int q = 0; q < irank; ++q) m &= m - 1;
+                            src = __ffsll((long long)m) - 1;
+                        }
+                        const float ox = __shfl(o.x, src), oy = __shfl(o.y, src), oz = __shfl(o.z, src);
+                        const float dx = __shfl(dirx, src);
+                        const float rx = __shfl(r.x, src), ry = __shfl(r.y, src), rz = __shfl(r.z, src);
+                        const float mx = __shfl(marg.x, src), my = __shfl(marg.y, src), mz = __shfl(marg.z, src);
+                        const float tm = __shfl(time, src), am = __shfl(amb, src), bd = __shfl(bound, src);
+                        const int en = __shfl(entry, src);
+                        if (take) {
+                            o = mk3(ox, oy, oz); dirx = dx; r = mk3(rx, ry, rz); marg = mk3(mx, my, mz);
+                            time = tm; amb = am;
+                            payi[PAY_RAY_IDX * TRACE_BLOCK] = payi[PAY_RAY_IDX * TRACE_BLOCK + (src - lane)];
+                            pay[PAY_DY * TRACE_BLOCK] = pay[PAY_DY * TRACE_BLOCK + (src - lane)];
+                            pay[PAY_DZ * TRACE_BLOCK] = pay[PAY_DZ * TRACE_BLOCK + (src - lane)];
+                            payi[PAY_PENDING * TRACE_BLOCK] = 0;
+                            best_t = bd; bound = bd; best_prim = -1;      // nothing at or beyond the giver's bound can win
+                            sp = sbase = 0; xf.id = -2; prim_i = prim_end = 0;
+                            plane = src; cur = en; has_ray = true;
+                            if (COUNT) { ray_steps = 0; ++dbg.v[3]; }
+                        }
+                        any_parts = true;
+                    }
                 }
             }
         }
         if (!__any(has_ray)) { if (exhausted && chunk_next >= chunk_end) break; else continue; }
+
+        // pruning bound: own best, and for a donated part whatever its parent has found meanwhile (all lanes take part)
+        bound = fminf(bound, best_t);
+        if (any_parts) bound = fminf(bound, __shfl(bound, plane));
 
         // a lane that arrived at a leaf (root, descent or pop) unpacks its primitive run: no memory round trip of its own
         if (has_ray && cur < 0) {
@@ -385,7 +480,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
 
         // ---------------- one unit of work per lane: a node step or a primitive test ----------------
         const bool in_leaf = has_ray && cur == CUR_IN_LEAF;
-        const bool at_node = has_ray && cur >= 0 && cur < CUR_IN_LEAF;
+        const bool at_node = has_ray && cur >= 0 && cur < CUR_WAIT;
         const int n_leaf = __popcll(__ballot(in_leaf)), n_node = __popcll(__ballot(at_node));
         const bool run_tri = n_leaf > 0 && (n_leaf >= sc.p.tri_min_lanes || n_leaf >= n_node);      // wave-uniform
         const bool do_tri = in_leaf && run_tri;
@@ -407,7 +502,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                 float tn, lb;
                 int c = slab_fast(mnx[i], mny[i], mnz[i], mxx[i], mxy[i], mxz[i], o, r, marg, amb, tn, lb);
                 if (c == 2) lb = -FLT_MAX;                        // undecided: no pruning either
-                if (cref[i] == DEV_REF_EMPTY || lb > best_t) c = 0;
+                if (cref[i] == DEV_REF_EMPTY || lb > bound) c = 0;
                 // an undecided INTERNAL child is entered (boxes nest: that is conservative); an undecided LEAF is decided exactly
                 if (c == 2) { if (cref[i] < 0) need_chain = true; else c = 1; }
                 cls[i] = c;
@@ -419,7 +514,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                 const int cch[4] = {__float_as_int(q7.x), __float_as_int(q7.y), __float_as_int(q7.z), __float_as_int(q7.w)};
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (cls[i] == 2) cls[i] = chain_visit(sc.chain, cch[i], o, d, r, amb) ? 1 : 0;
+                    if (cls[i] == 2) cls[i] = chain_visit(sc.chain, cch[i], o, mk3(dirx, pay[PAY_DY * TRACE_BLOCK], pay[PAY_DZ * TRACE_BLOCK]), r, amb) ? 1 : 0;
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) if (cls[i] == 0) key[i] = __int_as_float(0x7f800000);      // +inf: not taken, sorts last
@@ -442,22 +537,22 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                 }
                 sp += npush;
                 cur = cref[0];
-            } else if (sp == 0) cur = CUR_DONE;
+            } else if (sp == sbase) cur = CUR_DONE;
             else { --sp; cur = stack_pop(lds_col, ovf_col, ovf_stride, sp); }
         }
         if (run_tri) {
             if (do_tri) {
                 // ProcessIntersectionForLeafNode (BVHTree.cpp:177-190): fresh result per leaf, array order, accept t>0 && t < local-0.001
                 const int obj = __float_as_int(q3.x), kind = __float_as_int(q3.z);
-                if (obj != xf.id) enter_object<MOTION>(sc, obj, o, d, time, xf);
+                if (obj != xf.id) enter_object<MOTION>(sc, obj, o, mk3(dirx, pay[PAY_DY * TRACE_BLOCK], pay[PAY_DZ * TRACE_BLOCK]), time, xf);
                 Cand c;
                 bool ok;
                 if (kind == DEV_PRIM_TRIANGLE) {
                     if (COUNT) ++dbg.tris;
-                    ok = hit_triangle<MOTION>(sc, q0, q1, q2, xf, o.x, d.x, time, eps, c);
+                    ok = hit_triangle<MOTION>(sc, q0, q1, q2, xf, o.x, dirx, time, eps, c);
                 } else {
                     if (COUNT) ++dbg.sph;
-                    ok = hit_sphere<MOTION>(sc, q0, xf, o.x, d.x, time, c);
+                    ok = hit_sphere<MOTION>(sc, q0, xf, o.x, dirx, time, c);
                 }
                 if (ok && c.t > 0 && c.t < local_t - 0.001f) {
                     local_t = c.t; local_prim = prim_i;
@@ -466,13 +561,14 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                 }
                 if (++prim_i == prim_end) {
                     // ProcessIntersectionForInternalNode (BVHTree.cpp:192-206) reduced over all leaves: smaller t wins, ties
-                    // go to the leaf that comes later in DFS order (Q4); the leaf's first record index is that order
-                    if (local_prim >= 0 && (local_t < best_t || (local_t == best_t && leaf_key > best_leaf))) {
-                        best_t = local_t; best_prim = local_prim; best_leaf = leaf_key;
+                    // go to the leaf that comes later in DFS order (Q4); records are stored in that order, so the leaf's first
+                    // record index against the best record's index decides
+                    if (local_prim >= 0 && (local_t < best_t || (local_t == best_t && leaf_key > best_prim))) {
+                        best_t = local_t; best_prim = local_prim;
 #pragma unroll
                         for (int k = 0; k < 5; ++k) pay[(5 + k) * TRACE_BLOCK] = pay[k * TRACE_BLOCK];
                     }
-                    if (sp == 0) cur = CUR_DONE;
+                    if (sp == sbase) cur = CUR_DONE;
                     else { --sp; cur = stack_pop(lds_col, ovf_col, ovf_stride, sp); }
                 }
             }
