@@ -404,6 +404,10 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
         HIP_TRY(c, c->d_counters.ensure(1));
         HIP_TRY(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(DevCounters), s));
         d_counters = c->d_counters.p;
+        if (getenv("RT_TRACE_DEBUG")) {
+            static const unsigned long long one = 1;
+            HIP_TRY(c, hipMemcpyAsync(&d_counters->want_hist, &one, sizeof(one), hipMemcpyHostToDevice, s));
+        }
     }
 
     hipEvent_t ev_first = nullptr, ev_last = nullptr;

@@ -710,7 +710,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(4))
     dbg.nodes = dbg.boxes = dbg.tris = dbg.sph = 0;
     for (int k = 0; k < 10; ++k) dbg.v[k] = 0;
     trace_persistent<COUNT, MOTION, IO>(sc, io, n, fetch_counter, s_stack + threadIdx.x, s_pay + threadIdx.x, ovf + gtid, ovf_stride, dbg,
-                                        (COUNT && counters) ? &counters->hist[0] : nullptr);
+                                        (COUNT && counters && counters->want_hist) ? &counters->hist[0] : nullptr);
     flush_counters<COUNT>(counters, dbg.nodes, dbg.boxes, dbg.tris, dbg.sph);
     if (COUNT && counters) {
         for (int k = 0; k < 10; ++k) {

@@ -69,6 +69,7 @@ struct DevCounters {        // accumulated with atomics when counting is enabled
     // 0 outer iterations x64, 1 lanes holding a ray, 2 refill rounds x64, 3 lanes refilled, 4 node steps x64, 5 lanes stepping,
     // 6 leaf primitive iterations x64, 7 lanes testing a primitive, 8 exact-slab fallback rounds x64, 9 lanes needing it
     unsigned long long dbg[2][10];   // [closest | shadow]
+    unsigned long long want_hist;     // set by the host when RT_TRACE_DEBUG asks for the per-ray histogram (three atomics per ray)
     unsigned long long hist[96];      // rays by floor(log2(node steps))+1, [closest 16 | shadow 16]; then ticks (100 MHz) and steps per bucket
 };
 
