@@ -215,7 +215,7 @@ typedef struct rt_bvh_info {
     int64_t n_nodes;              /* internal + leaf nodes of the reference-topology tree */
     int64_t n_leaves;
     int32_t max_depth;
-    int32_t _pad;
+    int32_t n_wide_nodes;         /* 4-wide traversal nodes the reference tree was collapsed into (device layout) */
     int64_t n_leaf_prims;         /* leaf primitive references after duplicate removal    */
 } rt_bvh_info;
 

@@ -1348,7 +1348,7 @@ void orc_scene_destroy(void *h) {
 }
 int orc_bvh_info(void *h, rt_bvh_info *out) {
     orc::Scene *sc = static_cast<orc::Scene *>(h);
-    out->n_nodes = sc->nNodes; out->n_leaves = sc->nLeaves; out->max_depth = sc->maxDepth; out->n_leaf_prims = (int64_t)sc->primitives.size();
+    out->n_nodes = sc->nNodes; out->n_leaves = sc->nLeaves; out->max_depth = sc->maxDepth; out->n_wide_nodes = 0; out->n_leaf_prims = (int64_t)sc->primitives.size();
     return 0;
 }
 // Leaves in DFS (left-to-right) order: for leaf i, [start,end) into the re-ordered primitive array; prim_order[k] =

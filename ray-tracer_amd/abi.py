@@ -97,5 +97,5 @@ class Stats(C.Structure):
 
 
 class BvhInfo(C.Structure):
-    _fields_ = [("n_nodes", C.c_int64), ("n_leaves", C.c_int64), ("max_depth", C.c_int32), ("_pad", C.c_int32),
+    _fields_ = [("n_nodes", C.c_int64), ("n_leaves", C.c_int64), ("max_depth", C.c_int32), ("n_wide_nodes", C.c_int32),
                 ("n_leaf_prims", C.c_int64)]
