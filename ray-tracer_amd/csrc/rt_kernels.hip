@@ -260,7 +260,7 @@ __device__ __noinline__ bool chain_visit(const DevChain *chain, int node, f3 o, 
 //            store(sc, i, best)   writes the result of ray i.
 // ----------------------------------------------------------------------------------------------------
 #define CUR_DONE 0x7ffffffe      // lane finished its ray (stack empty), result not yet stored
-#define CUR_IN_LEAF 0x7ffffffd   // lane is walking the primitive run [prim_i, prim_end) of a leaf
+#define CUR_NONE 0x7ffffffd      // no node left to visit (stack empty); the lane may still hold a pending leaf
 #define CUR_WAIT 0x7ffffffc      // lane finished its own traversal and waits for parts it gave away
 #define TRACE_CHUNK 64           // rays a wave reserves per atomic
 #define REFILL_MIN_IDLE 8        // retire + refill once this many lanes are idle
@@ -468,22 +468,28 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
         bound = fminf(bound, best_t);
         if (any_parts) bound = fminf(bound, __shfl(bound, plane));
 
-        // a lane that arrived at a leaf (root, descent or pop) unpacks its primitive run: no memory round trip of its own
-        if (has_ray && cur < 0) {
+        // A lane that arrived at a leaf (root, descent or pop) unpacks its primitive run (no memory round trip of its own),
+        // keeps it as its PENDING leaf and goes on with the next node from its stack: the primitive path is expensive and
+        // runs only when enough lanes of the wave hold a pending leaf, and meanwhile the lane does not idle.  Visiting
+        // order does not matter for the result (§ exactness); the lane merely prunes with a slightly stale bound.  A lane
+        // that reaches a second leaf while one is pending waits for the primitive path.
+        if (has_ray && cur < 0 && !(prim_i < prim_end)) {
             const unsigned u = (unsigned)~cur;
             int start = (int)(u & ((1u << DEV_LEAF_START_BITS) - 1)), count = (int)(u >> DEV_LEAF_START_BITS);
             if (count == 0) { const DevLeaf lf = sc.leaves[start]; start = lf.start; count = lf.count; }
             prim_i = start; prim_end = start + count; leaf_key = start;
             local_t = FLT_MAX; local_prim = -1;
-            cur = CUR_IN_LEAF;
+            if (sp == sbase) cur = CUR_NONE;
+            else { --sp; cur = stack_pop(lds_col, ovf_col, ovf_stride, sp); }
         }
 
         // ---------------- one unit of work per lane: a node step or a primitive test ----------------
-        const bool in_leaf = has_ray && cur == CUR_IN_LEAF;
-        const bool at_node = has_ray && cur >= 0 && cur < CUR_WAIT;
-        const int n_leaf = __popcll(__ballot(in_leaf)), n_node = __popcll(__ballot(at_node));
+        const bool in_leaf = has_ray && prim_i < prim_end;
+        const bool can_node = has_ray && cur >= 0 && cur < CUR_WAIT;
+        const int n_leaf = __popcll(__ballot(in_leaf)), n_node = __popcll(__ballot(can_node));
         const bool run_tri = n_leaf > 0 && (n_leaf >= sc.p.tri_min_lanes || n_leaf >= n_node);      // wave-uniform
         const bool do_tri = in_leaf && run_tri;
+        const bool at_node = can_node && !do_tri;
         // every lane loads (idle lanes re-read record 0 of the node array): no merge of loaded and stale registers
         const float4 *rec = do_tri ? prims4 + 4 * (size_t)prim_i : nodes4 + (at_node ? 8 * (size_t)cur : 0);
         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
@@ -537,7 +543,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                 }
                 sp += npush;
                 cur = cref[0];
-            } else if (sp == sbase) cur = CUR_DONE;
+            } else if (sp == sbase) cur = CUR_NONE;
             else { --sp; cur = stack_pop(lds_col, ovf_col, ovf_stride, sp); }
         }
         if (run_tri) {
@@ -568,11 +574,11 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
 #pragma unroll
                         for (int k = 0; k < 5; ++k) pay[(5 + k) * TRACE_BLOCK] = pay[k * TRACE_BLOCK];
                     }
-                    if (sp == sbase) cur = CUR_DONE;
-                    else { --sp; cur = stack_pop(lds_col, ovf_col, ovf_stride, sp); }
+                    prim_i = prim_end = 0;
                 }
             }
         }
+        if (has_ray && cur == CUR_NONE && !(prim_i < prim_end)) cur = CUR_DONE;
     }
 }
 
