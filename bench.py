@@ -162,6 +162,10 @@ def main():
         cpu = {"value": round(sum(cst.rays) / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
                "sample": "every %dth row of the %dx%d frame (%d rows, %d rays, %.1f s), oracle/rt_oracle.cpp with %d threads, rows handed out dynamically"
                          % (args.cpu_row_step, nx, ny, len(range(0, ny, args.cpu_row_step)), sum(cst.rays), cpu_s, cores)}
+        # the reference's own split (DefaultRenderer.cpp:65-75): 8 threads, static row bands
+        t0 = time.perf_counter()
+        _, _, _, cst8 = osc.render(0, nthreads=8, dynamic=False, row_step=args.cpu_row_step, want_ids=False)
+        cpu["value_8_static_bands"] = round(sum(cst8.rays) / (time.perf_counter() - t0) / 1e6, 4)
         osc.close()
 
     bvh = ctx.bvh_info()
