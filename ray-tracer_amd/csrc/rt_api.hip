@@ -147,6 +147,7 @@ struct rt_ctx {
     std::vector<StreamLane> lanes;
     hipEvent_t ev_ready = nullptr;
     DevArray<int> d_pixels;
+    int pixels_key[5] = {0, 0, 0, 0, 0};    // (nx, ny, tile size, rank, world) the device pixel list was built for
     DevArray<int> d_overflow;               // rt_intersect_batch
     DevArray<int> d_counts;                 // rt_intersect_batch fetch counter
     DevArray<unsigned long long> d_kind;    // rays per kind
@@ -347,10 +348,16 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
 
     // owned pixels (interleaved tiles)
     const int64_t n_owned = rt_owned_pixel_count(cam->nx, cam->ny, opts->tile_size, opts->tile_rank, opts->tile_world);
-    std::vector<int32_t> pixels((size_t)n_owned);
-    rt_tile_pixel_order(cam->nx, cam->ny, opts->tile_size, opts->tile_rank, opts->tile_world, pixels.data());
-    HIP_TRY(c, c->d_pixels.ensure((size_t)std::max<int64_t>(1, n_owned)));
-    if (n_owned) HIP_TRY(c, hipMemcpyAsync(c->d_pixels.p, pixels.data(), (size_t)n_owned * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    // the pixel order only depends on (nx, ny, tile parameters): keep the device copy between frames
+    const int pix_key[5] = {cam->nx, cam->ny, opts->tile_size, opts->tile_rank, opts->tile_world};
+    if (std::memcmp(pix_key, c->pixels_key, sizeof(pix_key)) != 0 || !c->d_pixels.p) {
+        std::vector<int32_t> pixels((size_t)n_owned);
+        rt_tile_pixel_order(cam->nx, cam->ny, opts->tile_size, opts->tile_rank, opts->tile_world, pixels.data());
+        HIP_TRY(c, c->d_pixels.ensure((size_t)std::max<int64_t>(1, n_owned)));
+        if (n_owned) HIP_TRY(c, hipMemcpyAsync(c->d_pixels.p, pixels.data(), (size_t)n_owned * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipStreamSynchronize(s));          // `pixels` is pageable host memory that dies here
+        std::memcpy(c->pixels_key, pix_key, sizeof(pix_key));
+    }
 
     const bool compact = opts->compact_output != 0;
     const size_t n_out = compact ? (size_t)n_owned : (size_t)cam->nx * cam->ny;
