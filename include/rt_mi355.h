@@ -282,6 +282,10 @@ int rt_resolve_8bit(const float *hdr_rgb, int64_t n_pixels, uint8_t *out_rgb);
  * Any output pointer may be NULL. */
 typedef struct rt_host_bvh rt_host_bvh;
 int rt_host_bvh_build(const rt_scene_desc *scene, rt_host_bvh **out);
+/* The same view with the tree built by the GPU builder (what rt_scene_upload uses for scenes of >= 4096 primitives;
+ * here for any size).  Replaces BVHTree::BuildTree (reference src/BVHTree.cpp:39-153) with identical topology, primitive
+ * order and boxes; needs a HIP device (RT_ERR_NO_DEVICE otherwise). */
+int rt_host_bvh_build_gpu(const rt_scene_desc *scene, int hip_device_id, rt_host_bvh **out);
 int rt_host_bvh_info(const rt_host_bvh *bvh, rt_bvh_info *out);
 int rt_host_bvh_leaves(const rt_host_bvh *bvh, int64_t *leaf_start_end, int32_t *prim_order, float *leaf_boxes,
                        int64_t *dev_leaf_start_count, int32_t *dev_prim_shape);

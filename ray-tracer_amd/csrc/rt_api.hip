@@ -218,7 +218,7 @@ int rt_scene_upload(rt_ctx *c, const rt_scene_desc *scene) {
     if (!c) return RT_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     c->has_scene = false;
-    int rc = rt_build_host_scene(scene, c->host, c->error);
+    int rc = rt_build_host_scene(scene, c->host, c->error, /*gpu_build=*/1);
     if (rc != RT_OK) return rc;
     HostScene &h = c->host;
     for (const DevPrim &p : h.prims)
@@ -657,6 +657,18 @@ int rt_host_bvh_build(const rt_scene_desc *scene, rt_host_bvh **out) {
     rt_host_bvh *b = new rt_host_bvh();
     int rc = rt_build_host_scene(scene, b->hs, b->error);
     if (rc != RT_OK) { g_create_error = b->error; delete b; *out = nullptr; return rc; }
+    *out = b;
+    return RT_OK;
+}
+int rt_host_bvh_build_gpu(const rt_scene_desc *scene, int hip_device_id, rt_host_bvh **out) {
+    if (!out) return RT_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { g_create_error = "no HIP device available; the GPU BVH builder has no CPU fallback"; return RT_ERR_NO_DEVICE; }
+    if (hip_device_id < 0 || hip_device_id >= n || hipSetDevice(hip_device_id) != hipSuccess) { g_create_error = "hip_device_id out of range"; return RT_ERR_INVALID; }
+    rt_host_bvh *b = new rt_host_bvh();
+    int rc = rt_build_host_scene(scene, b->hs, b->error, /*gpu_build=*/2);
+    if (rc != RT_OK) { g_create_error = b->error; delete b; return rc; }
     *out = b;
     return RT_OK;
 }

@@ -28,7 +28,21 @@ struct HostScene {
     float scene_scale;                     // max |coordinate| of the root box
 };
 
-// Returns 0 or a negative rt_status; `err` receives a message.
-int rt_build_host_scene(const rt_scene_desc *d, HostScene &out, std::string &err);
+// One node of the reference-topology tree as a builder hands it to the flattener.
+struct RtBuildNode {
+    float lo[3], hi[3];
+    int32_t left, right;      // node indices, -1 for a leaf
+    int32_t start, end;       // range in the primitive order
+    int32_t depth;            // root = 1
+};
+
+// The reference's build on the GPU (rt_bvh_gpu.hip): same topology, order and boxes as the host builder.  pbox = n boxes of
+// 6 floats (lo, hi).  Needs a current HIP device.
+bool rt_bvh_gpu_build(const float *pbox, int64_t n, std::vector<int32_t> &order, std::vector<RtBuildNode> &nodes, int &max_depth, std::string &err);
+
+// Returns 0 or a negative rt_status; `err` receives a message.  gpu_build: build the tree with rt_bvh_gpu_build when the scene
+// has at least RT_GPU_BUILD_MIN_PRIMS primitives (the flattening stays on the host); the result is the same either way.
+#define RT_GPU_BUILD_MIN_PRIMS 4096
+int rt_build_host_scene(const rt_scene_desc *d, HostScene &out, std::string &err, int gpu_build = 0 /* 0 host, 1 auto, 2 always */);
 
 #endif

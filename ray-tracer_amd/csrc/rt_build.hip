@@ -8,25 +8,17 @@
 //                    re-ordering inside each side is the reference's), leaves keep index ranges
 //   flattening       new: preorder internal nodes with both child boxes, leaves numbered in DFS order (Q4 tie-break)
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 
 #include "rt_build.h"
+#include "rt_bvh_split.h"
 #include "rt_math.h"
 
 namespace {
-
-struct Aabb {
-    f3 lo, hi;
-};
-
-inline Aabb empty_box() { Aabb b; b.lo = mk3(1e9f, 1e9f, 1e9f); b.hi = mk3(-1e9f, -1e9f, -1e9f); return b; }   // acmath.h:754-758
-inline Aabb box_of(f3 a, f3 b) { Aabb r; r.hi = max3(a, b); r.lo = min3(a, b); return r; }                       // acmath.h:760-764
-inline Aabb merge(const Aabb &a, const Aabb &b) { return box_of(max3(a.hi, b.hi), min3(a.lo, b.lo)); }            // acmath.h:922
-inline Aabb merge(const Aabb &a, f3 p) { return box_of(max3(a.hi, p), min3(a.lo, p)); }                          // acmath.h:932
-inline float surface_area(const Aabb &b) { f3 e = b.hi - b.lo; return 2 * (e.x * e.y + e.y * e.z + e.x * e.z); } // acmath.h:830
-inline f3 centroid(const Aabb &b) { return (b.hi + b.lo) * 0.5f; }
-inline int widest_axis(f3 v) { return v.x > v.y ? (v.x > v.z ? 0 : 2) : (v.y > v.z ? 1 : 2); }                   // MaxElementIndex acmath.h:609
 
 // Transform::operator()(BoundingVolume3f) — the 8 corners through M, merged (acmath.h:1034-1050)
 Aabb transform_box(const float *M, const Aabb &b) {
@@ -53,11 +45,16 @@ struct Task {
     int32_t node, start, end, depth;
 };
 
-constexpr int kBins = 4;     // BVHTree.h:57
+constexpr int kBins = RT_BVH_BINS;
 
 }  // namespace
 
-int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err) {
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err, int gpu_build) {
+    const bool tm = getenv("RT_BUILD_TIMING") != nullptr;
+    double t_mark = now_s();
+    auto lap = [&](const char *what) { if (tm) { double t = now_s(); fprintf(stderr, "[rt build] %-28s %8.1f ms\n", what, (t - t_mark) * 1e3); t_mark = t; } };
     if (!d) { err = "scene description is NULL"; return RT_ERR_INVALID; }
     if (d->abi_version != RT_ABI_VERSION) { err = "rt_scene_desc.abi_version mismatch"; return RT_ERR_ABI; }
     if (d->n_vertices < 0 || d->n_triangles < 0 || d->n_spheres < 0 || d->n_objects < 0 || d->n_prims < 0 || d->n_materials < 0 ||
@@ -164,6 +161,7 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
         shapeBox[nT + s] = box_of(c + mk3(-rad, -rad, -rad), c + mk3(rad, rad, rad));
     }
 
+    lap("tables, triangles, normals");
     // ---- reference primitives and their world boxes (Q5, Q29) -------------------------------------
     const int64_t nP = d->n_prims;
     std::vector<Aabb> pbox(nP);
@@ -185,12 +183,29 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
         pshape[i] = (int32_t)si;
     }
 
+    lap("primitive boxes");
     // ---- BVH build (BVHTree.cpp:39-153), explicit work stack, nodes created in preorder ------------
     std::vector<int32_t> order(nP);
     for (int64_t i = 0; i < nP; ++i) order[i] = (int32_t)i;
     std::vector<BuildNode> bn;
     int maxDepth = 0;
-    if (nP > 0) {
+    bool built = false;
+    if (nP > 0 && (gpu_build == 2 || (gpu_build == 1 && nP >= RT_GPU_BUILD_MIN_PRIMS && !getenv("RT_HOST_BUILD")))) {
+        std::vector<float> flat(6 * (size_t)nP);
+        for (int64_t i = 0; i < nP; ++i) {
+            float *f = &flat[6 * (size_t)i];
+            f[0] = pbox[i].lo.x; f[1] = pbox[i].lo.y; f[2] = pbox[i].lo.z; f[3] = pbox[i].hi.x; f[4] = pbox[i].hi.y; f[5] = pbox[i].hi.z;
+        }
+        std::vector<RtBuildNode> gn;
+        if (!rt_bvh_gpu_build(flat.data(), nP, order, gn, maxDepth, err)) return RT_ERR_HIP;
+        bn.resize(gn.size());
+        for (size_t i = 0; i < gn.size(); ++i) {
+            bn[i].box.lo = ld3(gn[i].lo); bn[i].box.hi = ld3(gn[i].hi);
+            bn[i].left = gn[i].left; bn[i].right = gn[i].right; bn[i].start = gn[i].start; bn[i].end = gn[i].end; bn[i].depth = gn[i].depth;
+        }
+        built = true;
+    }
+    if (nP > 0 && !built) {
         bn.reserve((size_t)nP);
         std::vector<Task> work;
         bn.push_back(BuildNode());
@@ -207,37 +222,22 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
                 all = merge(all, pbox[order[i]]);
                 cen = merge(cen, centroid(pbox[order[i]]));
             }
-            const int ax = widest_axis(cen.hi - cen.lo);
-            const float clo = comp3(cen.lo, ax), chi = comp3(cen.hi, ax);
-            if (std::abs(chi - clo) < 0.00000001f) { bn[tk.node].box = all; continue; }
+            int ax;
+            float clo, chi;
+            if (!bvh_split_axis(cen, ax, clo, chi)) { bn[tk.node].box = all; continue; }
             int binCount[kBins] = {0, 0, 0, 0};
             Aabb binBox[kBins] = {empty_box(), empty_box(), empty_box(), empty_box()};
             for (int i = tk.start; i < tk.end; ++i) {
-                float cp = (comp3(centroid(pbox[order[i]]), ax) - clo) / (chi - clo);     // ClippedPosition acmath.h:942
-                int bin = kBins * cp;
+                int bin = bvh_bin_raw(pbox[order[i]], ax, clo, chi);
                 if (bin == kBins) --bin;
                 binCount[bin]++;
                 binBox[bin] = merge(binBox[bin], pbox[order[i]]);
             }
-            int fwdCount[kBins], bwdCount[kBins];
-            Aabb fwdBox[kBins], bwdBox[kBins];
-            fwdCount[0] = binCount[0]; fwdBox[0] = binBox[0];
-            for (int i = 1; i < kBins; ++i) { fwdBox[i] = merge(binBox[i], fwdBox[i - 1]); fwdCount[i] = binCount[i] + fwdCount[i - 1]; }
-            bwdCount[kBins - 1] = binCount[kBins - 1]; bwdBox[kBins - 1] = binBox[kBins - 1];
-            float cost[kBins];
-            const float saAll = surface_area(all);
-            cost[kBins - 1] = 0.125f + (fwdCount[kBins - 1] * surface_area(fwdBox[kBins - 1])) / saAll;
-            for (int i = kBins - 2; i >= 0; --i) {
-                bwdBox[i] = merge(binBox[i], bwdBox[i + 1]); bwdCount[i] = binCount[i] + bwdCount[i + 1];
-                cost[i] = 0.125f + (fwdCount[i] * surface_area(fwdBox[i]) + bwdCount[i + 1] * surface_area(bwdBox[i + 1])) / saAll;
-            }
-            float best = 1e9;
-            int split = -1;
-            for (int i = 0; i < kBins; ++i) if (best > cost[i]) { best = cost[i]; split = i; }
-            if (!(best < count)) { bn[tk.node].box = all; continue; }
+            int left_count = 0;
+            const int split = bvh_choose_split(binCount, binBox, all, count, left_count);
+            if (split < 0) { bn[tk.node].box = all; continue; }
             int32_t *mid = std::partition(&order[tk.start], &order[tk.end - 1] + 1, [&](int32_t p) {
-                int in = kBins * ((comp3(centroid(pbox[p]), ax) - clo) / (chi - clo));
-                return in <= split;
+                return bvh_bin_raw(pbox[p], ax, clo, chi) <= split;
             });
             const int32_t m = (int32_t)(mid - &order[0]);
             const int32_t l = (int32_t)bn.size();
@@ -251,6 +251,7 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
             if (bn[i].left >= 0) bn[i].box = merge(bn[bn[i].left].box, bn[bn[i].right].box);
     }
 
+    lap("reference BVH build");
     // ---- flatten ------------------------------------------------------------------------------------
     hs.nodes.clear(); hs.chain.clear(); hs.leaves.clear(); hs.prims.clear(); hs.ref_leaf_range.clear(); hs.leaf_boxes.clear();
     hs.ref_prim_order.resize(nP);
@@ -376,5 +377,6 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
     hs.params.prune_err = (4.0f * d->isect_eps + 2e-4f) * scale;   // eps*edge slack of the Cramer test + float error
     hs.info.n_nodes = (int64_t)bn.size(); hs.info.n_leaves = (int64_t)hs.leaves.size(); hs.info.max_depth = maxDepth; hs.info.n_wide_nodes = (int32_t)hs.nodes.size();
     hs.info.n_leaf_prims = (int64_t)hs.prims.size();
+    lap("flatten (leaves, wide nodes)");
     return RT_OK;
 }

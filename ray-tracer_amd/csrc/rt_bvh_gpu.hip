@@ -1,0 +1,370 @@
+// rt_bvh_gpu.hip — the reference's BVH build (BVHTree.cpp:39-153: top-down, 4-bin SAH on the widest centroid axis,
+// std::partition) executed level by level on the GPU, with the SAME topology, primitive order and boxes as the host
+// builder in rt_build.hip ("GPU BVH build replacing host BuildTree").
+//
+// Why the result is identical and not merely equivalent:
+//   * every per-node quantity is a min / max / count over the node's primitives (order independent) followed by the
+//     node-local arithmetic of rt_bvh_split.h, which host and device share;
+//   * std::partition (libstdc++, bidirectional) is a two-pointer sweep: elements already on the correct side stay, the
+//     k-th misplaced element from the left is swapped with the k-th misplaced element from the right.  That pairing is
+//     computed here with one prefix sum per level;
+//   * a node is a contiguous range of the order array, so the left-to-right leaf order is the order of range starts.
+// Only the sign of a zero box coordinate can differ (min/max of -0 and +0), which no later comparison can see.
+//
+// Per level: reduce boxes (wave-segmented by node) -> axis -> bin + reduce bins -> SAH -> flags -> scan -> pair -> swap ->
+// reassign -> finish one-primitive children.  All kernels are HBM streaming over the order array; atomics are issued once
+// per run of equal node ids inside a wave.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <string>
+#include <vector>
+
+#include "rt_build.h"
+#include "rt_bvh_split.h"
+
+namespace {
+
+#define GB_TRY(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); ok = false; goto done; } \
+    } while (0)
+
+// order-preserving map float <-> unsigned so that atomicMin / atomicMax work on floats
+__host__ __device__ __forceinline__ unsigned f2o(float f) {
+    const unsigned u = __builtin_bit_cast(unsigned, f);
+    return u ^ (0x80000000u | (unsigned)((int)u >> 31));          // negative: all bits flipped; positive: sign bit set
+}
+__host__ __device__ __forceinline__ float o2f(unsigned u) {
+    const unsigned top = (unsigned)((int)u >> 31);                   // all ones: was a positive float
+    return __builtin_bit_cast(float, u ^ (0x80000000u | ~top));
+}
+
+struct Tree {                 // structure of arrays, one entry per reference node (BFS numbering)
+    int *start, *end, *left, *depth;
+    float *box;               // [6] lo, hi
+};
+struct Level {                // scratch of the nodes of the current level, index = node - base
+    unsigned *all;            // [12]: lo3 (min), hi3 (max) of the boxes, then of the centroids
+    int *binCount;            // [4]
+    unsigned *binBox;         // [4][6]
+    int *ax, *split, *mid;    // split: -2 leaf, -1 undecided, 0..3
+    float *clo, *chi;
+};
+
+__global__ void k_level_init(Level lv, int cnt) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= cnt) return;
+    const unsigned elo = f2o(1e9f), ehi = f2o(-1e9f);
+    for (int k = 0; k < 3; ++k) { lv.all[12 * s + k] = elo; lv.all[12 * s + 3 + k] = ehi; lv.all[12 * s + 6 + k] = elo; lv.all[12 * s + 9 + k] = ehi; }
+    for (int b = 0; b < 4; ++b) {
+        lv.binCount[4 * s + b] = 0;
+        for (int k = 0; k < 3; ++k) { lv.binBox[24 * s + 6 * b + k] = elo; lv.binBox[24 * s + 6 * b + 3 + k] = ehi; }
+    }
+    lv.split[s] = -1;
+}
+
+// wave64 reduction over runs of equal `key` (runs are contiguous: a node is a range of positions); the first lane of each
+// run ends up with the run's min (MIN) or max
+template <bool MIN>
+__device__ __forceinline__ unsigned seg_reduce(unsigned v, int key) {
+    const int lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_down(v, off);
+        const int k2 = __shfl_down(key, off);
+        if (lane + off < 64 && k2 == key) v = MIN ? (o < v ? o : v) : (o > v ? o : v);
+    }
+    return v;
+}
+__device__ __forceinline__ int seg_sum(int v, int key) {
+    const int lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_down(v, off);
+        const int k2 = __shfl_down(key, off);
+        if (lane + off < 64 && k2 == key) v += o;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_reduce_boxes(const float *boxes, const int *order, const int *node_of, int n, int base, Level lv) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int nd = -1;
+    unsigned v[12];
+    const unsigned elo = 0xffffffffu, ehi = 0u;
+    for (int k = 0; k < 3; ++k) { v[k] = elo; v[3 + k] = ehi; v[6 + k] = elo; v[9 + k] = ehi; }
+    if (p < n) {
+        nd = node_of[p];
+        if (nd >= 0) {
+            const float *b = boxes + 6 * (size_t)order[p];
+            Aabb bx; bx.lo = ld3(b); bx.hi = ld3(b + 3);
+            const f3 c = centroid(bx);
+            v[0] = f2o(bx.lo.x); v[1] = f2o(bx.lo.y); v[2] = f2o(bx.lo.z); v[3] = f2o(bx.hi.x); v[4] = f2o(bx.hi.y); v[5] = f2o(bx.hi.z);
+            v[6] = f2o(c.x); v[7] = f2o(c.y); v[8] = f2o(c.z); v[9] = v[6]; v[10] = v[7]; v[11] = v[8];
+        }
+    }
+    const int prev = __shfl_up(nd, 1);
+    const bool head = nd >= 0 && (lane == 0 || prev != nd);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const bool is_min = (k % 6) < 3;
+        v[k] = is_min ? seg_reduce<true>(v[k], nd) : seg_reduce<false>(v[k], nd);
+    }
+    if (head) {
+        unsigned *a = lv.all + 12 * (size_t)(nd - base);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) { if ((k % 6) < 3) atomicMin(a + k, v[k]); else atomicMax(a + k, v[k]); }
+    }
+}
+
+__device__ __forceinline__ Aabb load_obox(const unsigned *u) {
+    Aabb b;
+    b.lo = mk3(o2f(u[0]), o2f(u[1]), o2f(u[2])); b.hi = mk3(o2f(u[3]), o2f(u[4]), o2f(u[5]));
+    return b;
+}
+
+__global__ void k_node_axis(Tree t, Level lv, int base, int cnt) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= cnt) return;
+    const int nd = base + s;
+    if (t.end[nd] - t.start[nd] <= 1) { lv.split[s] = -2; return; }           // already a finished leaf
+    const Aabb all = load_obox(lv.all + 12 * (size_t)s), cen = load_obox(lv.all + 12 * (size_t)s + 6);
+    int ax; float clo, chi;
+    if (!bvh_split_axis(cen, ax, clo, chi)) {                                    // leaf: all centroids coincide
+        lv.split[s] = -2; t.left[nd] = -1;
+        float *b = t.box + 6 * (size_t)nd;
+        b[0] = all.lo.x; b[1] = all.lo.y; b[2] = all.lo.z; b[3] = all.hi.x; b[4] = all.hi.y; b[5] = all.hi.z;
+        return;
+    }
+    lv.ax[s] = ax; lv.clo[s] = clo; lv.chi[s] = chi;
+}
+
+__global__ __launch_bounds__(256) void k_bin(const float *boxes, const int *order, const int *node_of, unsigned char *bin_raw, int n, int base, Level lv) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int nd = -1, bin = 0;
+    Aabb bx = empty_box();
+    if (p < n) {
+        nd = node_of[p];
+        if (nd >= 0 && lv.split[nd - base] == -2) nd = -1;
+        if (nd >= 0) {
+            const int s = nd - base;
+            const float *b = boxes + 6 * (size_t)order[p];
+            bx.lo = ld3(b); bx.hi = ld3(b + 3);
+            const int raw = bvh_bin_raw(bx, lv.ax[s], lv.clo[s], lv.chi[s]);
+            bin_raw[p] = (unsigned char)raw;
+            bin = raw == RT_BVH_BINS ? RT_BVH_BINS - 1 : raw;
+        }
+    }
+    // a wave that lies inside one node (the upper levels): reduce per bin in the wave, one set of atomics per bin
+    const int first = __shfl(nd, 0);
+    if (__all(nd == first)) {
+        if (first < 0) return;
+        const int s = first - base;
+        for (int b = 0; b < RT_BVH_BINS; ++b) {
+            const bool mine = bin == b;
+            const unsigned long long m = __ballot(mine);
+            if (!m) continue;
+            unsigned v[6];
+            v[0] = mine ? f2o(bx.lo.x) : 0xffffffffu; v[1] = mine ? f2o(bx.lo.y) : 0xffffffffu; v[2] = mine ? f2o(bx.lo.z) : 0xffffffffu;
+            v[3] = mine ? f2o(bx.hi.x) : 0u; v[4] = mine ? f2o(bx.hi.y) : 0u; v[5] = mine ? f2o(bx.hi.z) : 0u;
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                for (int off = 32; off > 0; off >>= 1) { const unsigned o = __shfl_xor(v[k], off); v[k] = k < 3 ? (o < v[k] ? o : v[k]) : (o > v[k] ? o : v[k]); }
+            if (lane == 0) {
+                atomicAdd(lv.binCount + 4 * (size_t)s + b, (int)__popcll(m));
+                unsigned *bb = lv.binBox + 24 * (size_t)s + 6 * b;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { if (k < 3) atomicMin(bb + k, v[k]); else atomicMax(bb + k, v[k]); }
+            }
+        }
+        return;
+    }
+    if (nd >= 0) {                                                               // small nodes: little contention
+        const int s = nd - base;
+        atomicAdd(lv.binCount + 4 * (size_t)s + bin, 1);
+        unsigned *bb = lv.binBox + 24 * (size_t)s + 6 * bin;
+        atomicMin(bb + 0, f2o(bx.lo.x)); atomicMin(bb + 1, f2o(bx.lo.y)); atomicMin(bb + 2, f2o(bx.lo.z));
+        atomicMax(bb + 3, f2o(bx.hi.x)); atomicMax(bb + 4, f2o(bx.hi.y)); atomicMax(bb + 5, f2o(bx.hi.z));
+    }
+}
+
+__global__ void k_split(Tree t, Level lv, int base, int cnt, int *next_node) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= cnt || lv.split[s] == -2) return;
+    const int nd = base + s;
+    const Aabb all = load_obox(lv.all + 12 * (size_t)s);
+    int binCount[RT_BVH_BINS];
+    Aabb binBox[RT_BVH_BINS];
+    for (int b = 0; b < RT_BVH_BINS; ++b) { binCount[b] = lv.binCount[4 * (size_t)s + b]; binBox[b] = load_obox(lv.binBox + 24 * (size_t)s + 6 * b); }
+    const int count = t.end[nd] - t.start[nd];
+    int left_count = 0;
+    const int split = bvh_choose_split(binCount, binBox, all, count, left_count);
+    float *b = t.box + 6 * (size_t)nd;
+    b[0] = all.lo.x; b[1] = all.lo.y; b[2] = all.lo.z; b[3] = all.hi.x; b[4] = all.hi.y; b[5] = all.hi.z;
+    if (split < 0) { lv.split[s] = -2; t.left[nd] = -1; return; }
+    const int c = atomicAdd(next_node, 2);
+    const int m = t.start[nd] + left_count;
+    lv.split[s] = split; lv.mid[s] = m;
+    t.left[nd] = c;
+    t.start[c] = t.start[nd]; t.end[c] = m; t.depth[c] = t.depth[nd] + 1; t.left[c] = -1;
+    t.start[c + 1] = m; t.end[c + 1] = t.end[nd]; t.depth[c + 1] = t.depth[nd] + 1; t.left[c + 1] = -1;
+}
+
+__global__ __launch_bounds__(256) void k_flags(const int *node_of, const unsigned char *bin_raw, int *flag, int n, int base, Level lv) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > n) return;
+    int f = 0;
+    if (p < n) {
+        const int nd = node_of[p];
+        if (nd >= 0) { const int sp = lv.split[nd - base]; if (sp >= 0 && (int)bin_raw[p] <= sp) f = 1; }
+    }
+    flag[p] = f;                                                                 // flag[n] = 0: scan[n] is the total
+}
+
+// std::partition's pairing: the k-th "false" left of the partition point swaps with the k-th "true" counted from the right end
+__global__ __launch_bounds__(256) void k_pairs(const int *node_of, const int *flag, const int *scan, int *pairL, int *pairR, int n, int base, Tree t, Level lv) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int nd = node_of[p];
+    if (nd < 0) return;
+    const int s = nd - base;
+    if (lv.split[s] < 0) return;
+    const int start = t.start[nd], m = lv.mid[s];
+    const int tb = scan[p] - scan[start];
+    if (p < m) { if (!flag[p]) pairL[start + (p - start) - tb] = p; }
+    else if (flag[p]) pairR[start + (m - start) - tb - 1] = p;
+}
+__global__ __launch_bounds__(256) void k_swap(const int *node_of, const int *scan, const int *pairL, const int *pairR, int *order, int n, int base, Tree t, Level lv) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int nd = node_of[p];
+    if (nd < 0) return;
+    const int s = nd - base;
+    if (lv.split[s] < 0) return;
+    const int start = t.start[nd], m = lv.mid[s];
+    const int npairs = (m - start) - (scan[m] - scan[start]);
+    const int k = p - start;
+    if (k < npairs) {
+        const int a = pairL[start + k], b = pairR[start + k];
+        const int oa = order[a], ob = order[b];
+        order[a] = ob; order[b] = oa;
+    }
+}
+__global__ __launch_bounds__(256) void k_assign(int *node_of, int n, int base, Tree t, Level lv) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int nd = node_of[p];
+    if (nd < 0) return;
+    const int s = nd - base;
+    if (lv.split[s] < 0) { node_of[p] = -1; return; }
+    node_of[p] = p < lv.mid[s] ? t.left[nd] : t.left[nd] + 1;
+}
+// children of one primitive are leaves at once (BVHTree.cpp:46-51): box = the primitive's box
+__global__ void k_children(Tree t, const float *boxes, const int *order, int *node_of, int base, int cnt) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= cnt) return;
+    const int nd = base + s;
+    if (t.end[nd] - t.start[nd] > 1) return;
+    const int p = t.start[nd];
+    const float *b = boxes + 6 * (size_t)order[p];
+    float *o = t.box + 6 * (size_t)nd;
+    for (int k = 0; k < 6; ++k) o[k] = b[k];
+    node_of[p] = -1;
+}
+__global__ void k_fill(int *a, int n, int v, int iota) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) a[p] = iota ? p : v;
+}
+
+template <typename T>
+hipError_t dalloc(T **p, size_t n) { return hipMalloc((void **)p, (n ? n : 1) * sizeof(T)); }
+
+}  // namespace
+
+// Host entry.  pbox: n boxes (lo.xyz, hi.xyz).  On success `order` holds the primitive permutation and `nodes` the tree in
+// breadth-first numbering (root = 0, children of a node adjacent).
+bool rt_bvh_gpu_build(const float *pbox, int64_t n64, std::vector<int32_t> &order, std::vector<RtBuildNode> &nodes, int &max_depth, std::string &err) {
+    const int n = (int)n64;
+    bool ok = true;
+    order.clear(); nodes.clear(); max_depth = 0;
+    if (n <= 0) return true;
+    float *d_box = nullptr; int *d_order = nullptr, *d_node_of = nullptr, *d_flag = nullptr, *d_scan = nullptr, *d_pairL = nullptr, *d_pairR = nullptr;
+    unsigned char *d_bin = nullptr; int *d_next = nullptr; void *d_tmp = nullptr; size_t tmp_bytes = 0;
+    Tree t = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    Level lv = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const size_t cap = 2 * (size_t)n + 2;
+    hipStream_t st = nullptr;
+    int n_nodes = 1, base = 0, cnt = 1;
+    const dim3 blk(256), grid_n((n + 1 + 255) / 256);
+    {
+        GB_TRY(dalloc(&d_box, 6 * (size_t)n)); GB_TRY(dalloc(&d_order, (size_t)n)); GB_TRY(dalloc(&d_node_of, (size_t)n));
+        GB_TRY(dalloc(&d_flag, (size_t)n + 1)); GB_TRY(dalloc(&d_scan, (size_t)n + 1)); GB_TRY(dalloc(&d_pairL, (size_t)n)); GB_TRY(dalloc(&d_pairR, (size_t)n));
+        GB_TRY(dalloc(&d_bin, (size_t)n)); GB_TRY(dalloc(&d_next, 1));
+        GB_TRY(dalloc(&t.start, cap)); GB_TRY(dalloc(&t.end, cap)); GB_TRY(dalloc(&t.left, cap)); GB_TRY(dalloc(&t.depth, cap)); GB_TRY(dalloc(&t.box, 6 * cap));
+        GB_TRY(dalloc(&lv.all, 12 * (size_t)n)); GB_TRY(dalloc(&lv.binCount, 4 * (size_t)n)); GB_TRY(dalloc(&lv.binBox, 24 * (size_t)n));
+        GB_TRY(dalloc(&lv.ax, (size_t)n)); GB_TRY(dalloc(&lv.split, (size_t)n)); GB_TRY(dalloc(&lv.mid, (size_t)n)); GB_TRY(dalloc(&lv.clo, (size_t)n)); GB_TRY(dalloc(&lv.chi, (size_t)n));
+        GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_flag, d_scan, n + 1));
+        GB_TRY(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
+        GB_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        GB_TRY(hipMemcpyAsync(d_box, pbox, 6 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_fill, grid_n, blk, 0, st, d_order, n, 0, 1);
+        hipLaunchKernelGGL(k_fill, grid_n, blk, 0, st, d_node_of, n, 0, 0);
+        {   // root
+            const int root[4] = {0, n, -1, 1};
+            GB_TRY(hipMemcpyAsync(t.start, &root[0], sizeof(int), hipMemcpyHostToDevice, st));
+            GB_TRY(hipMemcpyAsync(t.end, &root[1], sizeof(int), hipMemcpyHostToDevice, st));
+            GB_TRY(hipMemcpyAsync(t.left, &root[2], sizeof(int), hipMemcpyHostToDevice, st));
+            GB_TRY(hipMemcpyAsync(t.depth, &root[3], sizeof(int), hipMemcpyHostToDevice, st));
+            GB_TRY(hipMemcpyAsync(d_next, &n_nodes, sizeof(int), hipMemcpyHostToDevice, st));
+            GB_TRY(hipStreamSynchronize(st));
+        }
+        hipLaunchKernelGGL(k_children, dim3(1), dim3(64), 0, st, t, d_box, d_order, d_node_of, 0, 1);      // n == 1: the root is a leaf
+        while (cnt > 0) {
+            ++max_depth;
+            const dim3 grid_c((cnt + 255) / 256);
+            hipLaunchKernelGGL(k_level_init, grid_c, blk, 0, st, lv, cnt);
+            hipLaunchKernelGGL(k_reduce_boxes, grid_n, blk, 0, st, d_box, d_order, d_node_of, n, base, lv);
+            hipLaunchKernelGGL(k_node_axis, grid_c, blk, 0, st, t, lv, base, cnt);
+            hipLaunchKernelGGL(k_bin, grid_n, blk, 0, st, d_box, d_order, d_node_of, d_bin, n, base, lv);
+            hipLaunchKernelGGL(k_split, grid_c, blk, 0, st, t, lv, base, cnt, d_next);
+            hipLaunchKernelGGL(k_flags, grid_n, blk, 0, st, d_node_of, d_bin, d_flag, n, base, lv);
+            GB_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_flag, d_scan, n + 1, st));
+            hipLaunchKernelGGL(k_pairs, grid_n, blk, 0, st, d_node_of, d_flag, d_scan, d_pairL, d_pairR, n, base, t, lv);
+            hipLaunchKernelGGL(k_swap, grid_n, blk, 0, st, d_node_of, d_scan, d_pairL, d_pairR, d_order, n, base, t, lv);
+            hipLaunchKernelGGL(k_assign, grid_n, blk, 0, st, d_node_of, n, base, t, lv);
+            int next = 0;
+            GB_TRY(hipMemcpyAsync(&next, d_next, sizeof(int), hipMemcpyDeviceToHost, st));
+            GB_TRY(hipStreamSynchronize(st));
+            base += cnt; cnt = next - n_nodes; n_nodes = next;
+            if (cnt > 0) hipLaunchKernelGGL(k_children, dim3((cnt + 255) / 256), blk, 0, st, t, d_box, d_order, d_node_of, base, cnt);
+        }
+        GB_TRY(hipGetLastError());
+        // download
+        order.resize((size_t)n);
+        std::vector<int> hs((size_t)n_nodes), he((size_t)n_nodes), hl((size_t)n_nodes), hd((size_t)n_nodes);
+        std::vector<float> hb(6 * (size_t)n_nodes);
+        GB_TRY(hipMemcpyAsync(order.data(), d_order, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st));
+        GB_TRY(hipMemcpyAsync(hs.data(), t.start, (size_t)n_nodes * sizeof(int), hipMemcpyDeviceToHost, st));
+        GB_TRY(hipMemcpyAsync(he.data(), t.end, (size_t)n_nodes * sizeof(int), hipMemcpyDeviceToHost, st));
+        GB_TRY(hipMemcpyAsync(hl.data(), t.left, (size_t)n_nodes * sizeof(int), hipMemcpyDeviceToHost, st));
+        GB_TRY(hipMemcpyAsync(hd.data(), t.depth, (size_t)n_nodes * sizeof(int), hipMemcpyDeviceToHost, st));
+        GB_TRY(hipMemcpyAsync(hb.data(), t.box, 6 * (size_t)n_nodes * sizeof(float), hipMemcpyDeviceToHost, st));
+        GB_TRY(hipStreamSynchronize(st));
+        nodes.resize((size_t)n_nodes);
+        max_depth = 0;
+        for (int i = 0; i < n_nodes; ++i) {
+            RtBuildNode &b = nodes[(size_t)i];
+            for (int k = 0; k < 3; ++k) { b.lo[k] = hb[6 * (size_t)i + k]; b.hi[k] = hb[6 * (size_t)i + 3 + k]; }
+            b.left = hl[i]; b.right = hl[i] >= 0 ? hl[i] + 1 : -1; b.start = hs[i]; b.end = he[i]; b.depth = hd[i];
+            if (hd[i] > max_depth) max_depth = hd[i];
+        }
+    }
+done:
+    hipFree(d_box); hipFree(d_order); hipFree(d_node_of); hipFree(d_flag); hipFree(d_scan); hipFree(d_pairL); hipFree(d_pairR); hipFree(d_bin);
+    hipFree(d_next); hipFree(d_tmp); hipFree(t.start); hipFree(t.end); hipFree(t.left); hipFree(t.depth); hipFree(t.box);
+    hipFree(lv.all); hipFree(lv.binCount); hipFree(lv.binBox); hipFree(lv.ax); hipFree(lv.split); hipFree(lv.mid); hipFree(lv.clo); hipFree(lv.chi);
+    if (st) hipStreamDestroy(st);
+    return ok;
+}

@@ -85,12 +85,13 @@ def resolve_8bit(hdr):
     return out
 
 
-def host_bvh(soup):
-    """Host-only BVH view (no GPU): dict with info, reference leaf ranges / primitive order / boxes and device leaf runs."""
+def host_bvh(soup, gpu_device=None):
+    """BVH view: dict with info, reference leaf ranges / primitive order / boxes and device leaf runs.  Built on the host
+    (no GPU needed) or, with gpu_device, by the GPU builder."""
     L = library()
     d = soup.desc()
     h = C.c_void_p()
-    rc = L.rt_host_bvh_build(C.byref(d), C.byref(h))
+    rc = L.rt_host_bvh_build(C.byref(d), C.byref(h)) if gpu_device is None else L.rt_host_bvh_build_gpu(C.byref(d), int(gpu_device), C.byref(h))
     if rc != 0:
         raise RtError(rc, L.rt_last_error(None).decode())
     try:

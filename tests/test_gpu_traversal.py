@@ -103,3 +103,30 @@ def test_donation_on_long_rays(rt, orc, gpu_ctx):
     assert np.array_equal(g["shape"], c["shape"])
     assert np.array_equal(g["t"].view(np.uint32), c["t"].view(np.uint32))
     assert (c["shape"] >= 0).sum() > n // 10
+
+
+@pytest.mark.parametrize("name", ["cornellbox", "bunny", "scienceTree", "cornellbox_boxes_dynamic", "spheres", "metal_glass_plates"])
+def test_gpu_bvh_build_equals_host_build(rt, scene_path, name):
+    """The GPU builder (level-synchronous, parallel partition) must produce the reference's tree exactly: same leaves in the
+    same order, same primitive order, same boxes (== on floats: only the sign of a zero may differ)."""
+    soup = rt.SceneSoup.load(scene_path(name))
+    h = rt.renderer.host_bvh(soup)
+    g = rt.renderer.host_bvh(soup, gpu_device=0)
+    for k in ("n_nodes", "n_leaves", "max_depth", "n_wide_nodes", "n_leaf_prims"):
+        assert getattr(h["info"], k) == getattr(g["info"], k), k
+    assert np.array_equal(h["leaf_start_end"], g["leaf_start_end"])
+    assert np.array_equal(h["prim_order"], g["prim_order"])
+    assert np.array_equal(h["leaf_boxes"], g["leaf_boxes"])
+    assert np.array_equal(h["dev_leaf_start_count"], g["dev_leaf_start_count"])
+    assert np.array_equal(h["dev_prim_shape"], g["dev_prim_shape"])
+
+
+def test_gpu_bvh_build_large(rt):
+    """1M-triangle config-2 scene and an instanced scene (transformed boxes, motion-blur boxes): GPU build == host build."""
+    for soup in (synth.dragon_standin_scene(200_000, 64, 48), synth.instanced_scene(6, 5000, 64, 48, 4)):
+        h = rt.renderer.host_bvh(soup)
+        g = rt.renderer.host_bvh(soup, gpu_device=0)
+        assert h["info"].n_nodes == g["info"].n_nodes and h["info"].max_depth == g["info"].max_depth
+        assert np.array_equal(h["leaf_start_end"], g["leaf_start_end"])
+        assert np.array_equal(h["prim_order"], g["prim_order"])
+        assert np.array_equal(h["leaf_boxes"], g["leaf_boxes"])
