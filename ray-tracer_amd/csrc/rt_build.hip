@@ -191,13 +191,9 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
     int maxDepth = 0;
     bool built = false;
     if (nP > 0 && (gpu_build == 2 || (gpu_build == 1 && nP >= RT_GPU_BUILD_MIN_PRIMS && !getenv("RT_HOST_BUILD")))) {
-        std::vector<float> flat(6 * (size_t)nP);
-        for (int64_t i = 0; i < nP; ++i) {
-            float *f = &flat[6 * (size_t)i];
-            f[0] = pbox[i].lo.x; f[1] = pbox[i].lo.y; f[2] = pbox[i].lo.z; f[3] = pbox[i].hi.x; f[4] = pbox[i].hi.y; f[5] = pbox[i].hi.z;
-        }
+        static_assert(sizeof(Aabb) == 6 * sizeof(float), "Aabb must be six packed floats (lo, hi)");
         std::vector<RtBuildNode> gn;
-        if (!rt_bvh_gpu_build(flat.data(), nP, order, gn, maxDepth, err)) return RT_ERR_HIP;
+        if (!rt_bvh_gpu_build(reinterpret_cast<const float *>(pbox.data()), nP, order, gn, maxDepth, err)) return RT_ERR_HIP;
         bn.resize(gn.size());
         for (size_t i = 0; i < gn.size(); ++i) {
             bn[i].box.lo = ld3(gn[i].lo); bn[i].box.hi = ld3(gn[i].hi);

@@ -17,6 +17,9 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -87,22 +90,42 @@ __device__ __forceinline__ int seg_sum(int v, int key) {
     return v;
 }
 
+#define GB_ITEMS 8             // consecutive positions per thread in the two reduction kernels (fewer, fatter atomics)
+
+__device__ __forceinline__ void atomic_box12(unsigned *a, const unsigned *v) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { if ((k % 6) < 3) atomicMin(a + k, v[k]); else atomicMax(a + k, v[k]); }
+}
+
+// Box of the primitives and box of their centroids, per node.  A thread walks GB_ITEMS consecutive positions and keeps a
+// running box while the node stays the same; completed runs go out as atomics at once, the thread's last run is first
+// combined across the wave (runs of equal node are contiguous), so a wave inside one node issues a single set of atomics.
 __global__ __launch_bounds__(256) void k_reduce_boxes(const float *boxes, const int *order, const int *node_of, int n, int base, Level lv) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p0 = (blockIdx.x * blockDim.x + threadIdx.x) * GB_ITEMS;
     const int lane = threadIdx.x & 63;
     int nd = -1;
     unsigned v[12];
     const unsigned elo = 0xffffffffu, ehi = 0u;
+#pragma unroll
     for (int k = 0; k < 3; ++k) { v[k] = elo; v[3 + k] = ehi; v[6 + k] = elo; v[9 + k] = ehi; }
-    if (p < n) {
-        nd = node_of[p];
-        if (nd >= 0) {
-            const float *b = boxes + 6 * (size_t)order[p];
-            Aabb bx; bx.lo = ld3(b); bx.hi = ld3(b + 3);
-            const f3 c = centroid(bx);
-            v[0] = f2o(bx.lo.x); v[1] = f2o(bx.lo.y); v[2] = f2o(bx.lo.z); v[3] = f2o(bx.hi.x); v[4] = f2o(bx.hi.y); v[5] = f2o(bx.hi.z);
-            v[6] = f2o(c.x); v[7] = f2o(c.y); v[8] = f2o(c.z); v[9] = v[6]; v[10] = v[7]; v[11] = v[8];
+    for (int j = 0; j < GB_ITEMS; ++j) {
+        const int p = p0 + j;
+        if (p >= n) break;
+        const int ndj = node_of[p];
+        if (ndj != nd) {
+            if (nd >= 0) atomic_box12(lv.all + 12 * (size_t)(nd - base), v);
+            nd = ndj;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { v[k] = elo; v[3 + k] = ehi; v[6 + k] = elo; v[9 + k] = ehi; }
         }
+        if (ndj < 0) continue;
+        const float *b = boxes + 6 * (size_t)order[p];
+        Aabb bx; bx.lo = ld3(b); bx.hi = ld3(b + 3);
+        const f3 c = centroid(bx);
+        const unsigned w[12] = {f2o(bx.lo.x), f2o(bx.lo.y), f2o(bx.lo.z), f2o(bx.hi.x), f2o(bx.hi.y), f2o(bx.hi.z),
+                                f2o(c.x), f2o(c.y), f2o(c.z), f2o(c.x), f2o(c.y), f2o(c.z)};
+#pragma unroll
+        for (int k = 0; k < 12; ++k) v[k] = ((k % 6) < 3) ? (w[k] < v[k] ? w[k] : v[k]) : (w[k] > v[k] ? w[k] : v[k]);
     }
     const int prev = __shfl_up(nd, 1);
     const bool head = nd >= 0 && (lane == 0 || prev != nd);
@@ -111,11 +134,7 @@ __global__ __launch_bounds__(256) void k_reduce_boxes(const float *boxes, const 
         const bool is_min = (k % 6) < 3;
         v[k] = is_min ? seg_reduce<true>(v[k], nd) : seg_reduce<false>(v[k], nd);
     }
-    if (head) {
-        unsigned *a = lv.all + 12 * (size_t)(nd - base);
-#pragma unroll
-        for (int k = 0; k < 12; ++k) { if ((k % 6) < 3) atomicMin(a + k, v[k]); else atomicMax(a + k, v[k]); }
-    }
+    if (head) atomic_box12(lv.all + 12 * (size_t)(nd - base), v);
 }
 
 __device__ __forceinline__ Aabb load_obox(const unsigned *u) {
@@ -140,53 +159,80 @@ __global__ void k_node_axis(Tree t, Level lv, int base, int cnt) {
     lv.ax[s] = ax; lv.clo[s] = clo; lv.chi[s] = chi;
 }
 
+// Bin of every primitive (stored for the partition) and count / box per (node, bin).  Same scheme: a thread whose
+// GB_ITEMS positions lie in one node accumulates four local bins; a wave whose threads all lie in the same node combines
+// them before the atomics.
 __global__ __launch_bounds__(256) void k_bin(const float *boxes, const int *order, const int *node_of, unsigned char *bin_raw, int n, int base, Level lv) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p0 = (blockIdx.x * blockDim.x + threadIdx.x) * GB_ITEMS;
     const int lane = threadIdx.x & 63;
-    int nd = -1, bin = 0;
-    Aabb bx = empty_box();
-    if (p < n) {
-        nd = node_of[p];
+    const unsigned elo = 0xffffffffu, ehi = 0u;
+    int cnt[RT_BVH_BINS] = {0, 0, 0, 0};
+    unsigned bb[RT_BVH_BINS][6];
+#pragma unroll
+    for (int b = 0; b < RT_BVH_BINS; ++b) { bb[b][0] = bb[b][1] = bb[b][2] = elo; bb[b][3] = bb[b][4] = bb[b][5] = ehi; }
+    int nd0 = -2;                   // node of the thread's first position (-1: finished leaf, -2: none seen); the local bins are its
+    for (int j = 0; j < GB_ITEMS; ++j) {
+        const int p = p0 + j;
+        if (p >= n) break;
+        int nd = node_of[p];
         if (nd >= 0 && lv.split[nd - base] == -2) nd = -1;
-        if (nd >= 0) {
-            const int s = nd - base;
-            const float *b = boxes + 6 * (size_t)order[p];
-            bx.lo = ld3(b); bx.hi = ld3(b + 3);
-            const int raw = bvh_bin_raw(bx, lv.ax[s], lv.clo[s], lv.chi[s]);
-            bin_raw[p] = (unsigned char)raw;
-            bin = raw == RT_BVH_BINS ? RT_BVH_BINS - 1 : raw;
+        if (nd0 == -2) nd0 = nd;
+        if (nd < 0) continue;
+        const int s = nd - base;
+        const float *b = boxes + 6 * (size_t)order[p];
+        Aabb bx; bx.lo = ld3(b); bx.hi = ld3(b + 3);
+        const int raw = bvh_bin_raw(bx, lv.ax[s], lv.clo[s], lv.chi[s]);
+        bin_raw[p] = (unsigned char)raw;
+        const int bin = raw == RT_BVH_BINS ? RT_BVH_BINS - 1 : raw;
+        const unsigned w[6] = {f2o(bx.lo.x), f2o(bx.lo.y), f2o(bx.lo.z), f2o(bx.hi.x), f2o(bx.hi.y), f2o(bx.hi.z)};
+        if (nd == nd0) {
+#pragma unroll
+            for (int q = 0; q < RT_BVH_BINS; ++q)
+                if (q == bin) {
+                    ++cnt[q];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) bb[q][k] = k < 3 ? (w[k] < bb[q][k] ? w[k] : bb[q][k]) : (w[k] > bb[q][k] ? w[k] : bb[q][k]);
+                }
+        } else {                    // a second node inside this thread's positions: small nodes, little contention
+            atomicAdd(lv.binCount + 4 * (size_t)s + bin, 1);
+            unsigned *g = lv.binBox + 24 * (size_t)s + 6 * bin;
+            atomicMin(g + 0, w[0]); atomicMin(g + 1, w[1]); atomicMin(g + 2, w[2]);
+            atomicMax(g + 3, w[3]); atomicMax(g + 4, w[4]); atomicMax(g + 5, w[5]);
         }
     }
-    // a wave that lies inside one node (the upper levels): reduce per bin in the wave, one set of atomics per bin
-    const int first = __shfl(nd, 0);
-    if (__all(nd == first)) {
+    // local bins belong to node nd0 (if >= 0)
+    const int mine = nd0 >= 0 ? nd0 : -1;
+    const int first = __shfl(mine, 0);
+    if (__all(mine == first)) {
         if (first < 0) return;
         const int s = first - base;
+#pragma unroll
         for (int b = 0; b < RT_BVH_BINS; ++b) {
-            const bool mine = bin == b;
-            const unsigned long long m = __ballot(mine);
-            if (!m) continue;
-            unsigned v[6];
-            v[0] = mine ? f2o(bx.lo.x) : 0xffffffffu; v[1] = mine ? f2o(bx.lo.y) : 0xffffffffu; v[2] = mine ? f2o(bx.lo.z) : 0xffffffffu;
-            v[3] = mine ? f2o(bx.hi.x) : 0u; v[4] = mine ? f2o(bx.hi.y) : 0u; v[5] = mine ? f2o(bx.hi.z) : 0u;
+            int c = cnt[b];
+            for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+            if (c == 0) continue;
 #pragma unroll
             for (int k = 0; k < 6; ++k)
-                for (int off = 32; off > 0; off >>= 1) { const unsigned o = __shfl_xor(v[k], off); v[k] = k < 3 ? (o < v[k] ? o : v[k]) : (o > v[k] ? o : v[k]); }
+                for (int off = 32; off > 0; off >>= 1) { const unsigned o = __shfl_xor(bb[b][k], off); bb[b][k] = k < 3 ? (o < bb[b][k] ? o : bb[b][k]) : (o > bb[b][k] ? o : bb[b][k]); }
             if (lane == 0) {
-                atomicAdd(lv.binCount + 4 * (size_t)s + b, (int)__popcll(m));
-                unsigned *bb = lv.binBox + 24 * (size_t)s + 6 * b;
+                atomicAdd(lv.binCount + 4 * (size_t)s + b, c);
+                unsigned *g = lv.binBox + 24 * (size_t)s + 6 * b;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) { if (k < 3) atomicMin(bb + k, v[k]); else atomicMax(bb + k, v[k]); }
+                for (int k = 0; k < 6; ++k) { if (k < 3) atomicMin(g + k, bb[b][k]); else atomicMax(g + k, bb[b][k]); }
             }
         }
         return;
     }
-    if (nd >= 0) {                                                               // small nodes: little contention
-        const int s = nd - base;
-        atomicAdd(lv.binCount + 4 * (size_t)s + bin, 1);
-        unsigned *bb = lv.binBox + 24 * (size_t)s + 6 * bin;
-        atomicMin(bb + 0, f2o(bx.lo.x)); atomicMin(bb + 1, f2o(bx.lo.y)); atomicMin(bb + 2, f2o(bx.lo.z));
-        atomicMax(bb + 3, f2o(bx.hi.x)); atomicMax(bb + 4, f2o(bx.hi.y)); atomicMax(bb + 5, f2o(bx.hi.z));
+    if (mine >= 0) {
+        const int s = mine - base;
+#pragma unroll
+        for (int b = 0; b < RT_BVH_BINS; ++b) {
+            if (cnt[b] == 0) continue;
+            atomicAdd(lv.binCount + 4 * (size_t)s + b, cnt[b]);
+            unsigned *g = lv.binBox + 24 * (size_t)s + 6 * b;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { if (k < 3) atomicMin(g + k, bb[b][k]); else atomicMax(g + k, bb[b][k]); }
+        }
     }
 }
 
@@ -288,6 +334,10 @@ hipError_t dalloc(T **p, size_t n) { return hipMalloc((void **)p, (n ? n : 1) * 
 bool rt_bvh_gpu_build(const float *pbox, int64_t n64, std::vector<int32_t> &order, std::vector<RtBuildNode> &nodes, int &max_depth, std::string &err) {
     const int n = (int)n64;
     bool ok = true;
+    const bool tm = getenv("RT_BUILD_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_mark = now();
+    auto lap = [&](const char *what) { if (tm) { const double t = now(); fprintf(stderr, "[rt gpu build] %-24s %8.2f ms\n", what, t - t_mark); t_mark = t; } };
     order.clear(); nodes.clear(); max_depth = 0;
     if (n <= 0) return true;
     float *d_box = nullptr; int *d_order = nullptr, *d_node_of = nullptr, *d_flag = nullptr, *d_scan = nullptr, *d_pairL = nullptr, *d_pairR = nullptr;
@@ -297,7 +347,7 @@ bool rt_bvh_gpu_build(const float *pbox, int64_t n64, std::vector<int32_t> &orde
     const size_t cap = 2 * (size_t)n + 2;
     hipStream_t st = nullptr;
     int n_nodes = 1, base = 0, cnt = 1;
-    const dim3 blk(256), grid_n((n + 1 + 255) / 256);
+    const dim3 blk(256), grid_n((n + 1 + 255) / 256), grid_r((n + 256 * GB_ITEMS - 1) / (256 * GB_ITEMS));
     {
         GB_TRY(dalloc(&d_box, 6 * (size_t)n)); GB_TRY(dalloc(&d_order, (size_t)n)); GB_TRY(dalloc(&d_node_of, (size_t)n));
         GB_TRY(dalloc(&d_flag, (size_t)n + 1)); GB_TRY(dalloc(&d_scan, (size_t)n + 1)); GB_TRY(dalloc(&d_pairL, (size_t)n)); GB_TRY(dalloc(&d_pairR, (size_t)n));
@@ -308,6 +358,7 @@ bool rt_bvh_gpu_build(const float *pbox, int64_t n64, std::vector<int32_t> &orde
         GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_flag, d_scan, n + 1));
         GB_TRY(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
         GB_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        lap("allocate");
         GB_TRY(hipMemcpyAsync(d_box, pbox, 6 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_fill, grid_n, blk, 0, st, d_order, n, 0, 1);
         hipLaunchKernelGGL(k_fill, grid_n, blk, 0, st, d_node_of, n, 0, 0);
@@ -320,14 +371,15 @@ bool rt_bvh_gpu_build(const float *pbox, int64_t n64, std::vector<int32_t> &orde
             GB_TRY(hipMemcpyAsync(d_next, &n_nodes, sizeof(int), hipMemcpyHostToDevice, st));
             GB_TRY(hipStreamSynchronize(st));
         }
+        lap("upload boxes");
         hipLaunchKernelGGL(k_children, dim3(1), dim3(64), 0, st, t, d_box, d_order, d_node_of, 0, 1);      // n == 1: the root is a leaf
         while (cnt > 0) {
             ++max_depth;
             const dim3 grid_c((cnt + 255) / 256);
             hipLaunchKernelGGL(k_level_init, grid_c, blk, 0, st, lv, cnt);
-            hipLaunchKernelGGL(k_reduce_boxes, grid_n, blk, 0, st, d_box, d_order, d_node_of, n, base, lv);
+            hipLaunchKernelGGL(k_reduce_boxes, grid_r, blk, 0, st, d_box, d_order, d_node_of, n, base, lv);
             hipLaunchKernelGGL(k_node_axis, grid_c, blk, 0, st, t, lv, base, cnt);
-            hipLaunchKernelGGL(k_bin, grid_n, blk, 0, st, d_box, d_order, d_node_of, d_bin, n, base, lv);
+            hipLaunchKernelGGL(k_bin, grid_r, blk, 0, st, d_box, d_order, d_node_of, d_bin, n, base, lv);
             hipLaunchKernelGGL(k_split, grid_c, blk, 0, st, t, lv, base, cnt, d_next);
             hipLaunchKernelGGL(k_flags, grid_n, blk, 0, st, d_node_of, d_bin, d_flag, n, base, lv);
             GB_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_flag, d_scan, n + 1, st));
@@ -341,6 +393,7 @@ bool rt_bvh_gpu_build(const float *pbox, int64_t n64, std::vector<int32_t> &orde
             if (cnt > 0) hipLaunchKernelGGL(k_children, dim3((cnt + 255) / 256), blk, 0, st, t, d_box, d_order, d_node_of, base, cnt);
         }
         GB_TRY(hipGetLastError());
+        lap("levels");
         // download
         order.resize((size_t)n);
         std::vector<int> hs((size_t)n_nodes), he((size_t)n_nodes), hl((size_t)n_nodes), hd((size_t)n_nodes);
@@ -352,6 +405,7 @@ bool rt_bvh_gpu_build(const float *pbox, int64_t n64, std::vector<int32_t> &orde
         GB_TRY(hipMemcpyAsync(hd.data(), t.depth, (size_t)n_nodes * sizeof(int), hipMemcpyDeviceToHost, st));
         GB_TRY(hipMemcpyAsync(hb.data(), t.box, 6 * (size_t)n_nodes * sizeof(float), hipMemcpyDeviceToHost, st));
         GB_TRY(hipStreamSynchronize(st));
+        lap("download");
         nodes.resize((size_t)n_nodes);
         max_depth = 0;
         for (int i = 0; i < n_nodes; ++i) {
@@ -360,11 +414,13 @@ bool rt_bvh_gpu_build(const float *pbox, int64_t n64, std::vector<int32_t> &orde
             b.left = hl[i]; b.right = hl[i] >= 0 ? hl[i] + 1 : -1; b.start = hs[i]; b.end = he[i]; b.depth = hd[i];
             if (hd[i] > max_depth) max_depth = hd[i];
         }
+        lap("convert");
     }
 done:
     hipFree(d_box); hipFree(d_order); hipFree(d_node_of); hipFree(d_flag); hipFree(d_scan); hipFree(d_pairL); hipFree(d_pairR); hipFree(d_bin);
     hipFree(d_next); hipFree(d_tmp); hipFree(t.start); hipFree(t.end); hipFree(t.left); hipFree(t.depth); hipFree(t.box);
     hipFree(lv.all); hipFree(lv.binCount); hipFree(lv.binBox); hipFree(lv.ax); hipFree(lv.split); hipFree(lv.mid); hipFree(lv.clo); hipFree(lv.chi);
     if (st) hipStreamDestroy(st);
+    lap("free");
     return ok;
 }
