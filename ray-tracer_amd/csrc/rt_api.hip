@@ -218,15 +218,28 @@ int rt_scene_upload(rt_ctx *c, const rt_scene_desc *scene) {
     if (!c) return RT_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     c->has_scene = false;
-    int rc = rt_build_host_scene(scene, c->host, c->error, /*gpu_build=*/1);
+    if (scene && scene->abi_version == RT_ABI_VERSION && scene->n_spheres > 0 && scene->sph_object && scene->objects)
+        for (int64_t i = 0; i < scene->n_spheres; ++i) {                 // Sphere.cpp:128 dereferences the transform unconditionally (Q9)
+            const int32_t ob = scene->sph_object[i];
+            if (ob >= 0 && ob < scene->n_objects && !(scene->objects[ob].flags & RT_OBJ_HAS_XFORM)) { c->error = "sphere object without a transform"; return RT_ERR_INVALID; }
+        }
+    RtGpuScene gs;
+    int rc = rt_build_host_scene(scene, c->host, c->error, /*gpu_build=*/1, &gs);
     if (rc != RT_OK) return rc;
     HostScene &h = c->host;
-    for (const DevPrim &p : h.prims)
-        if (p.kind == DEV_PRIM_SPHERE && !(h.objects[p.object].flags & DEV_OBJ_HAS_XFORM)) { c->error = "sphere object without a transform"; return RT_ERR_INVALID; }
-    UPLOAD(c, c->d_nodes, h.nodes);
-    UPLOAD(c, c->d_chain, h.chain);
-    UPLOAD(c, c->d_leaves, h.leaves);
-    UPLOAD(c, c->d_prims, h.prims);
+    if (gs.prims) {       // built and flattened on the device (rt_bvh_gpu.hip): adopt the arrays
+        c->d_nodes.release(); c->d_chain.release(); c->d_leaves.release(); c->d_prims.release();
+        c->d_nodes.p = gs.nodes; c->d_nodes.cap = (size_t)gs.n_wide;
+        c->d_chain.p = gs.chain; c->d_chain.cap = (size_t)gs.n_nodes;
+        c->d_leaves.p = gs.leaves; c->d_leaves.cap = (size_t)gs.n_leaves;
+        c->d_prims.p = gs.prims; c->d_prims.cap = (size_t)gs.n_leaf_prims;
+        if (!c->d_nodes.p) HIP_TRY(c, c->d_nodes.ensure(1));          // a one-leaf scene has no wide node
+    } else {
+        UPLOAD(c, c->d_nodes, h.nodes);
+        UPLOAD(c, c->d_chain, h.chain);
+        UPLOAD(c, c->d_leaves, h.leaves);
+        UPLOAD(c, c->d_prims, h.prims);
+    }
     UPLOAD(c, c->d_objects, h.objects);
     UPLOAD(c, c->d_verts, h.verts);
     UPLOAD(c, c->d_tri_vert, h.tri_vert);

@@ -40,9 +40,26 @@ struct RtBuildNode {
 // 6 floats (lo, hi).  Needs a current HIP device.
 bool rt_bvh_gpu_build(const float *pbox, int64_t n, std::vector<int32_t> &order, std::vector<RtBuildNode> &nodes, int &max_depth, std::string &err);
 
+// The traversal arrays as the device flattener leaves them (device memory owned by the caller) + what the host needs to know.
+struct RtGpuScene {
+    DevNode4 *nodes = nullptr;
+    DevChain *chain = nullptr;
+    DevLeaf *leaves = nullptr;
+    DevPrim *prims = nullptr;
+    int64_t n_wide = 0, n_nodes = 0, n_leaves = 0, n_leaf_prims = 0;
+    int32_t root = 0;
+    float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
+    int max_depth = 0, stack_bound = 0;
+};
+// Build and flatten on the GPU: shape_rec = one DevPrim per shape, pshape[i] = shape of reference primitive i (host arrays).
+bool rt_bvh_gpu_build_flatten(const float *pbox, int64_t n, const DevPrim *shape_rec, int64_t n_shapes, const int32_t *pshape, RtGpuScene &out, std::string &err);
+
 // Returns 0 or a negative rt_status; `err` receives a message.  gpu_build: build the tree with rt_bvh_gpu_build when the scene
 // has at least RT_GPU_BUILD_MIN_PRIMS primitives (the flattening stays on the host); the result is the same either way.
 #define RT_GPU_BUILD_MIN_PRIMS 4096
-int rt_build_host_scene(const rt_scene_desc *d, HostScene &out, std::string &err, int gpu_build = 0 /* 0 host, 1 auto, 2 always */);
+// device_out != nullptr (and the scene large enough): build + flatten on the GPU; nodes / chain / leaves / prims of `out` stay
+// empty and *device_out receives the device arrays.
+int rt_build_host_scene(const rt_scene_desc *d, HostScene &out, std::string &err, int gpu_build = 0 /* 0 host, 1 auto, 2 always */,
+                        RtGpuScene *device_out = nullptr);
 
 #endif

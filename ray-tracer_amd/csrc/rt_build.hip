@@ -51,7 +51,7 @@ constexpr int kBins = RT_BVH_BINS;
 
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err, int gpu_build) {
+int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err, int gpu_build, RtGpuScene *device_out) {
     const bool tm = getenv("RT_BUILD_TIMING") != nullptr;
     double t_mark = now_s();
     auto lap = [&](const char *what) { if (tm) { double t = now_s(); fprintf(stderr, "[rt build] %-28s %8.1f ms\n", what, (t - t_mark) * 1e3); t_mark = t; } };
@@ -189,8 +189,16 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
     for (int64_t i = 0; i < nP; ++i) order[i] = (int32_t)i;
     std::vector<BuildNode> bn;
     int maxDepth = 0;
-    bool built = false;
-    if (nP > 0 && (gpu_build == 2 || (gpu_build == 1 && nP >= RT_GPU_BUILD_MIN_PRIMS && !getenv("RT_HOST_BUILD")))) {
+    bool built = false, device_done = false;
+    const bool want_gpu = nP > 0 && (gpu_build == 2 || (gpu_build == 1 && nP >= RT_GPU_BUILD_MIN_PRIMS && !getenv("RT_HOST_BUILD")));
+    if (want_gpu && device_out && !getenv("RT_HOST_FLATTEN")) {
+        // build AND flatten on the device: the traversal arrays never exist on the host
+        static_assert(sizeof(Aabb) == 6 * sizeof(float), "Aabb must be six packed floats (lo, hi)");
+        if (!rt_bvh_gpu_build_flatten(reinterpret_cast<const float *>(pbox.data()), nP, shapeRec.data(), (int64_t)shapeRec.size(), pshape.data(), *device_out, err)) return RT_ERR_HIP;
+        maxDepth = device_out->max_depth;
+        built = device_done = true;
+    }
+    if (!built && nP > 0 && (gpu_build == 2 || (gpu_build == 1 && nP >= RT_GPU_BUILD_MIN_PRIMS && !getenv("RT_HOST_BUILD")))) {
         static_assert(sizeof(Aabb) == 6 * sizeof(float), "Aabb must be six packed floats (lo, hi)");
         std::vector<RtBuildNode> gn;
         if (!rt_bvh_gpu_build(reinterpret_cast<const float *>(pbox.data()), nP, order, gn, maxDepth, err)) return RT_ERR_HIP;
@@ -255,6 +263,12 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
     std::memset(&hs.params, 0, sizeof(hs.params));
     hs.params.root = RT_NO_ROOT;
     auto store3 = [](float *dst, f3 v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; };
+    if (device_done) {
+        hs.ref_prim_order.clear();
+        hs.params.root = device_out->root;
+        for (int k = 0; k < 3; ++k) { hs.params.root_min[k] = device_out->root_lo[k]; hs.params.root_max[k] = device_out->root_hi[k]; }
+        hs.params.stack_bound = device_out->stack_bound;
+    }
     if (!bn.empty()) {
         // DFS numbering of leaves (left to right); primitive records in that order
         int wideDepth = 0;
@@ -367,12 +381,16 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
     hs.params.has_motion = 0;
     for (const DevObject &o : hs.objects) if (o.flags & DEV_OBJ_MOTION) hs.params.has_motion = 1;
     float scale = 1.0f;
-    if (!bn.empty())
+    if (!bn.empty() || device_done)
         for (int k = 0; k < 3; ++k) scale = std::max(scale, std::max(std::fabs(hs.params.root_min[k]), std::fabs(hs.params.root_max[k])));
     hs.scene_scale = scale;
     hs.params.prune_err = (4.0f * d->isect_eps + 2e-4f) * scale;   // eps*edge slack of the Cramer test + float error
     hs.info.n_nodes = (int64_t)bn.size(); hs.info.n_leaves = (int64_t)hs.leaves.size(); hs.info.max_depth = maxDepth; hs.info.n_wide_nodes = (int32_t)hs.nodes.size();
     hs.info.n_leaf_prims = (int64_t)hs.prims.size();
+    if (device_done) {
+        hs.info.n_nodes = device_out->n_nodes; hs.info.n_leaves = device_out->n_leaves; hs.info.n_wide_nodes = (int32_t)device_out->n_wide;
+        hs.info.n_leaf_prims = device_out->n_leaf_prims;
+    }
     lap("flatten (leaves, wide nodes)");
     return RT_OK;
 }

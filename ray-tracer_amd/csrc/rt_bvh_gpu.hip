@@ -324,103 +324,315 @@ __global__ void k_fill(int *a, int n, int v, int iota) {
     if (p < n) a[p] = iota ? p : v;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Flattening on the device: leaves in left-to-right order (= order of range starts), primitive records with repeated shapes
+// inside a leaf removed, packed leaf references, one DevChain per reference node, 4-wide collapse level by level.
+// Mirrors the host flattener in rt_build.hip; the wide nodes are numbered breadth-first here (preorder there), which no
+// result depends on.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mark_leaves(Tree t, int n_nodes, int *flag) {
+    const int nd = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nd < n_nodes && t.left[nd] < 0) flag[t.start[nd]] = 1;
+}
+// per leaf: number of distinct shapes (a second reference to a shape inside one leaf can never win)
+__global__ __launch_bounds__(256) void k_leaf_unique(Tree t, int n_nodes, const int *order, const int *pshape, const int *leaf_at, int *uniq) {
+    const int nd = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nd >= n_nodes || t.left[nd] >= 0) return;
+    const int s = t.start[nd], e = t.end[nd];
+    int c = 0;
+    for (int i = s; i < e; ++i) {
+        const int sh = pshape[order[i]];
+        bool dup = false;
+        for (int j = s; j < i && !dup; ++j) dup = pshape[order[j]] == sh;
+        c += dup ? 0 : 1;
+    }
+    uniq[leaf_at[s]] = c;
+}
+__global__ __launch_bounds__(256) void k_leaf_write(Tree t, int n_nodes, const int *order, const int *pshape, const int *leaf_at, const int *dev_start,
+                                                   const float4 *shape_rec, float4 *prims, DevLeaf *leaves, int *leaf_ref, int *status) {
+    const int nd = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nd >= n_nodes || t.left[nd] >= 0) return;
+    const int s = t.start[nd], e = t.end[nd];
+    const int li = leaf_at[s], ds = dev_start[li];
+    int c = 0;
+    for (int i = s; i < e; ++i) {
+        const int sh = pshape[order[i]];
+        bool dup = false;
+        for (int j = s; j < i && !dup; ++j) dup = pshape[order[j]] == sh;
+        if (dup) continue;
+        const float4 *src = shape_rec + 4 * (size_t)sh;
+        float4 *dst = prims + 4 * (size_t)(ds + c);
+        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+        ++c;
+    }
+    leaves[li].start = ds; leaves[li].count = c;
+    if (c >= 1 && c <= DEV_LEAF_MAX_PACKED && ds < (1 << DEV_LEAF_START_BITS)) leaf_ref[nd] = ~(int)(((unsigned)c << DEV_LEAF_START_BITS) | (unsigned)ds);
+    else { if (li >= (1 << DEV_LEAF_START_BITS)) *status = 1; leaf_ref[nd] = ~li; }
+}
+__global__ __launch_bounds__(256) void k_chain(Tree t, int n_nodes, DevChain *chain) {
+    const int nd = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nd >= n_nodes) return;
+    const float *b = t.box + 6 * (size_t)nd;
+    DevChain &c = chain[nd];
+    c.lo[0] = b[0]; c.lo[1] = b[1]; c.lo[2] = b[2]; c.hi[0] = b[3]; c.hi[1] = b[4]; c.hi[2] = b[5];
+    c._pad = 0;
+    if (nd == 0) c.parent = -1;
+    const int l = t.left[nd];
+    if (l >= 0) { chain[l].parent = nd; chain[l + 1].parent = nd; }      // distinct fields per thread: no race
+}
+// one level of the 4-wide collapse: every work item is (reference node, wide node index)
+__global__ __launch_bounds__(256) void k_collapse(Tree t, const int *leaf_ref, const int2 *work, int n_work, int2 *next_work, int *next_count,
+                                                int *wide_count, DevNode4 *wide) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_work) return;
+    const int bnode = work[w].x, windex = work[w].y;
+    int kids[4];
+    int nk = 2;
+    kids[0] = t.left[bnode]; kids[1] = kids[0] + 1;
+    while (nk < 4) {
+        int pick = -1;
+        float area = -1.0f;
+        for (int i = 0; i < nk; ++i)
+            if (t.left[kids[i]] >= 0) {
+                const float *b = t.box + 6 * (size_t)kids[i];
+                Aabb bx; bx.lo = ld3(b); bx.hi = ld3(b + 3);
+                const float a = surface_area(bx);
+                if (a > area) { area = a; pick = i; }
+            }
+        if (pick < 0) break;
+        const int open = kids[pick];
+        for (int i = nk; i > pick + 1; --i) kids[i] = kids[i - 1];           // keep left-to-right order
+        kids[pick] = t.left[open]; kids[pick + 1] = t.left[open] + 1;
+        ++nk;
+    }
+    int n_int = 0;
+    for (int i = 0; i < nk; ++i) n_int += t.left[kids[i]] >= 0 ? 1 : 0;
+    int wbase = 0, qbase = 0;
+    if (n_int) { wbase = atomicAdd(wide_count, n_int); qbase = atomicAdd(next_count, n_int); }
+    DevNode4 &o = wide[windex];
+    int k_int = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (i < nk) {
+            const float *b = t.box + 6 * (size_t)kids[i];
+            o.minx[i] = b[0]; o.miny[i] = b[1]; o.minz[i] = b[2]; o.maxx[i] = b[3]; o.maxy[i] = b[4]; o.maxz[i] = b[5];
+            o.chain[i] = kids[i];
+            if (t.left[kids[i]] >= 0) {
+                o.ref[i] = wbase + k_int;
+                next_work[qbase + k_int] = make_int2(kids[i], wbase + k_int);
+                ++k_int;
+            } else o.ref[i] = leaf_ref[kids[i]];
+        } else {
+            o.minx[i] = o.miny[i] = o.minz[i] = 0.0f; o.maxx[i] = o.maxy[i] = o.maxz[i] = 0.0f;
+            o.ref[i] = DEV_REF_EMPTY; o.chain[i] = -1;
+        }
+    }
+}
+
 template <typename T>
 hipError_t dalloc(T **p, size_t n) { return hipMalloc((void **)p, (n ? n : 1) * sizeof(T)); }
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Device state of one build.
+struct GpuBuild {
+    int n = 0, n_nodes = 1, max_depth = 0;
+    float *d_box = nullptr; int *d_order = nullptr, *d_node_of = nullptr, *d_flag = nullptr, *d_scan = nullptr, *d_pairL = nullptr, *d_pairR = nullptr;
+    unsigned char *d_bin = nullptr; int *d_next = nullptr; void *d_tmp = nullptr; size_t tmp_bytes = 0;
+    Tree t = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    Level lv = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t st = nullptr;
+    bool tm = false;
+    double t_mark = 0;
+    void lap(const char *what) { if (tm) { const double tn = now_ms(); fprintf(stderr, "[rt gpu build] %-24s %8.2f ms\n", what, tn - t_mark); t_mark = tn; } }
+
+    bool build(const float *pbox, int n_, std::string &err) {
+        n = n_;
+        bool ok = true;
+        tm = getenv("RT_BUILD_TIMING") != nullptr;
+        t_mark = now_ms();
+        const size_t cap = 2 * (size_t)n + 2;
+        int base = 0, cnt = 1;
+        const dim3 blk(256), grid_n((n + 1 + 255) / 256), grid_r((n + 256 * GB_ITEMS - 1) / (256 * GB_ITEMS));
+        {
+            GB_TRY(dalloc(&d_box, 6 * (size_t)n)); GB_TRY(dalloc(&d_order, (size_t)n)); GB_TRY(dalloc(&d_node_of, (size_t)n));
+            GB_TRY(dalloc(&d_flag, (size_t)n + 1)); GB_TRY(dalloc(&d_scan, (size_t)n + 1)); GB_TRY(dalloc(&d_pairL, (size_t)n)); GB_TRY(dalloc(&d_pairR, (size_t)n));
+            GB_TRY(dalloc(&d_bin, (size_t)n)); GB_TRY(dalloc(&d_next, 4));
+            GB_TRY(dalloc(&t.start, cap)); GB_TRY(dalloc(&t.end, cap)); GB_TRY(dalloc(&t.left, cap)); GB_TRY(dalloc(&t.depth, cap)); GB_TRY(dalloc(&t.box, 6 * cap));
+            GB_TRY(dalloc(&lv.all, 12 * (size_t)n)); GB_TRY(dalloc(&lv.binCount, 4 * (size_t)n)); GB_TRY(dalloc(&lv.binBox, 24 * (size_t)n));
+            GB_TRY(dalloc(&lv.ax, (size_t)n)); GB_TRY(dalloc(&lv.split, (size_t)n)); GB_TRY(dalloc(&lv.mid, (size_t)n)); GB_TRY(dalloc(&lv.clo, (size_t)n)); GB_TRY(dalloc(&lv.chi, (size_t)n));
+            GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_flag, d_scan, n + 1));
+            GB_TRY(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
+            GB_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            lap("allocate");
+            GB_TRY(hipMemcpyAsync(d_box, pbox, 6 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_fill, grid_n, blk, 0, st, d_order, n, 0, 1);
+            hipLaunchKernelGGL(k_fill, grid_n, blk, 0, st, d_node_of, n, 0, 0);
+            {   // root
+                const int root[4] = {0, n, -1, 1};
+                GB_TRY(hipMemcpyAsync(t.start, &root[0], sizeof(int), hipMemcpyHostToDevice, st));
+                GB_TRY(hipMemcpyAsync(t.end, &root[1], sizeof(int), hipMemcpyHostToDevice, st));
+                GB_TRY(hipMemcpyAsync(t.left, &root[2], sizeof(int), hipMemcpyHostToDevice, st));
+                GB_TRY(hipMemcpyAsync(t.depth, &root[3], sizeof(int), hipMemcpyHostToDevice, st));
+                GB_TRY(hipMemcpyAsync(d_next, &n_nodes, sizeof(int), hipMemcpyHostToDevice, st));
+                GB_TRY(hipStreamSynchronize(st));
+            }
+            lap("upload boxes");
+            hipLaunchKernelGGL(k_children, dim3(1), dim3(64), 0, st, t, d_box, d_order, d_node_of, 0, 1);      // n == 1: the root is a leaf
+            while (cnt > 0) {
+                ++max_depth;
+                const dim3 grid_c((cnt + 255) / 256);
+                hipLaunchKernelGGL(k_level_init, grid_c, blk, 0, st, lv, cnt);
+                hipLaunchKernelGGL(k_reduce_boxes, grid_r, blk, 0, st, d_box, d_order, d_node_of, n, base, lv);
+                hipLaunchKernelGGL(k_node_axis, grid_c, blk, 0, st, t, lv, base, cnt);
+                hipLaunchKernelGGL(k_bin, grid_r, blk, 0, st, d_box, d_order, d_node_of, d_bin, n, base, lv);
+                hipLaunchKernelGGL(k_split, grid_c, blk, 0, st, t, lv, base, cnt, d_next);
+                hipLaunchKernelGGL(k_flags, grid_n, blk, 0, st, d_node_of, d_bin, d_flag, n, base, lv);
+                GB_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_flag, d_scan, n + 1, st));
+                hipLaunchKernelGGL(k_pairs, grid_n, blk, 0, st, d_node_of, d_flag, d_scan, d_pairL, d_pairR, n, base, t, lv);
+                hipLaunchKernelGGL(k_swap, grid_n, blk, 0, st, d_node_of, d_scan, d_pairL, d_pairR, d_order, n, base, t, lv);
+                hipLaunchKernelGGL(k_assign, grid_n, blk, 0, st, d_node_of, n, base, t, lv);
+                int next = 0;
+                GB_TRY(hipMemcpyAsync(&next, d_next, sizeof(int), hipMemcpyDeviceToHost, st));
+                GB_TRY(hipStreamSynchronize(st));
+                base += cnt; cnt = next - n_nodes; n_nodes = next;
+                if (cnt > 0) hipLaunchKernelGGL(k_children, dim3((cnt + 255) / 256), blk, 0, st, t, d_box, d_order, d_node_of, base, cnt);
+            }
+            GB_TRY(hipGetLastError());
+            // the depth of a leaf created on the last level is max_depth as counted (root = 1)
+            lap("levels");
+        }
+    done:
+        return ok;
+    }
+    void release() {
+        hipFree(d_box); hipFree(d_order); hipFree(d_node_of); hipFree(d_flag); hipFree(d_scan); hipFree(d_pairL); hipFree(d_pairR); hipFree(d_bin);
+        hipFree(d_next); hipFree(d_tmp); hipFree(t.start); hipFree(t.end); hipFree(t.left); hipFree(t.depth); hipFree(t.box);
+        hipFree(lv.all); hipFree(lv.binCount); hipFree(lv.binBox); hipFree(lv.ax); hipFree(lv.split); hipFree(lv.mid); hipFree(lv.clo); hipFree(lv.chi);
+        if (st) hipStreamDestroy(st);
+        lap("free");
+    }
+};
 
 }  // namespace
 
 // Host entry.  pbox: n boxes (lo.xyz, hi.xyz).  On success `order` holds the primitive permutation and `nodes` the tree in
 // breadth-first numbering (root = 0, children of a node adjacent).
 bool rt_bvh_gpu_build(const float *pbox, int64_t n64, std::vector<int32_t> &order, std::vector<RtBuildNode> &nodes, int &max_depth, std::string &err) {
-    const int n = (int)n64;
-    bool ok = true;
-    const bool tm = getenv("RT_BUILD_TIMING") != nullptr;
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_mark = now();
-    auto lap = [&](const char *what) { if (tm) { const double t = now(); fprintf(stderr, "[rt gpu build] %-24s %8.2f ms\n", what, t - t_mark); t_mark = t; } };
     order.clear(); nodes.clear(); max_depth = 0;
-    if (n <= 0) return true;
-    float *d_box = nullptr; int *d_order = nullptr, *d_node_of = nullptr, *d_flag = nullptr, *d_scan = nullptr, *d_pairL = nullptr, *d_pairR = nullptr;
-    unsigned char *d_bin = nullptr; int *d_next = nullptr; void *d_tmp = nullptr; size_t tmp_bytes = 0;
-    Tree t = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    Level lv = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    const size_t cap = 2 * (size_t)n + 2;
-    hipStream_t st = nullptr;
-    int n_nodes = 1, base = 0, cnt = 1;
-    const dim3 blk(256), grid_n((n + 1 + 255) / 256), grid_r((n + 256 * GB_ITEMS - 1) / (256 * GB_ITEMS));
-    {
-        GB_TRY(dalloc(&d_box, 6 * (size_t)n)); GB_TRY(dalloc(&d_order, (size_t)n)); GB_TRY(dalloc(&d_node_of, (size_t)n));
-        GB_TRY(dalloc(&d_flag, (size_t)n + 1)); GB_TRY(dalloc(&d_scan, (size_t)n + 1)); GB_TRY(dalloc(&d_pairL, (size_t)n)); GB_TRY(dalloc(&d_pairR, (size_t)n));
-        GB_TRY(dalloc(&d_bin, (size_t)n)); GB_TRY(dalloc(&d_next, 1));
-        GB_TRY(dalloc(&t.start, cap)); GB_TRY(dalloc(&t.end, cap)); GB_TRY(dalloc(&t.left, cap)); GB_TRY(dalloc(&t.depth, cap)); GB_TRY(dalloc(&t.box, 6 * cap));
-        GB_TRY(dalloc(&lv.all, 12 * (size_t)n)); GB_TRY(dalloc(&lv.binCount, 4 * (size_t)n)); GB_TRY(dalloc(&lv.binBox, 24 * (size_t)n));
-        GB_TRY(dalloc(&lv.ax, (size_t)n)); GB_TRY(dalloc(&lv.split, (size_t)n)); GB_TRY(dalloc(&lv.mid, (size_t)n)); GB_TRY(dalloc(&lv.clo, (size_t)n)); GB_TRY(dalloc(&lv.chi, (size_t)n));
-        GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_flag, d_scan, n + 1));
-        GB_TRY(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
-        GB_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        lap("allocate");
-        GB_TRY(hipMemcpyAsync(d_box, pbox, 6 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_fill, grid_n, blk, 0, st, d_order, n, 0, 1);
-        hipLaunchKernelGGL(k_fill, grid_n, blk, 0, st, d_node_of, n, 0, 0);
-        {   // root
-            const int root[4] = {0, n, -1, 1};
-            GB_TRY(hipMemcpyAsync(t.start, &root[0], sizeof(int), hipMemcpyHostToDevice, st));
-            GB_TRY(hipMemcpyAsync(t.end, &root[1], sizeof(int), hipMemcpyHostToDevice, st));
-            GB_TRY(hipMemcpyAsync(t.left, &root[2], sizeof(int), hipMemcpyHostToDevice, st));
-            GB_TRY(hipMemcpyAsync(t.depth, &root[3], sizeof(int), hipMemcpyHostToDevice, st));
-            GB_TRY(hipMemcpyAsync(d_next, &n_nodes, sizeof(int), hipMemcpyHostToDevice, st));
-            GB_TRY(hipStreamSynchronize(st));
-        }
-        lap("upload boxes");
-        hipLaunchKernelGGL(k_children, dim3(1), dim3(64), 0, st, t, d_box, d_order, d_node_of, 0, 1);      // n == 1: the root is a leaf
-        while (cnt > 0) {
-            ++max_depth;
-            const dim3 grid_c((cnt + 255) / 256);
-            hipLaunchKernelGGL(k_level_init, grid_c, blk, 0, st, lv, cnt);
-            hipLaunchKernelGGL(k_reduce_boxes, grid_r, blk, 0, st, d_box, d_order, d_node_of, n, base, lv);
-            hipLaunchKernelGGL(k_node_axis, grid_c, blk, 0, st, t, lv, base, cnt);
-            hipLaunchKernelGGL(k_bin, grid_r, blk, 0, st, d_box, d_order, d_node_of, d_bin, n, base, lv);
-            hipLaunchKernelGGL(k_split, grid_c, blk, 0, st, t, lv, base, cnt, d_next);
-            hipLaunchKernelGGL(k_flags, grid_n, blk, 0, st, d_node_of, d_bin, d_flag, n, base, lv);
-            GB_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_flag, d_scan, n + 1, st));
-            hipLaunchKernelGGL(k_pairs, grid_n, blk, 0, st, d_node_of, d_flag, d_scan, d_pairL, d_pairR, n, base, t, lv);
-            hipLaunchKernelGGL(k_swap, grid_n, blk, 0, st, d_node_of, d_scan, d_pairL, d_pairR, d_order, n, base, t, lv);
-            hipLaunchKernelGGL(k_assign, grid_n, blk, 0, st, d_node_of, n, base, t, lv);
-            int next = 0;
-            GB_TRY(hipMemcpyAsync(&next, d_next, sizeof(int), hipMemcpyDeviceToHost, st));
-            GB_TRY(hipStreamSynchronize(st));
-            base += cnt; cnt = next - n_nodes; n_nodes = next;
-            if (cnt > 0) hipLaunchKernelGGL(k_children, dim3((cnt + 255) / 256), blk, 0, st, t, d_box, d_order, d_node_of, base, cnt);
-        }
-        GB_TRY(hipGetLastError());
-        lap("levels");
-        // download
+    if (n64 <= 0) return true;
+    GpuBuild g;
+    bool ok = g.build(pbox, (int)n64, err);
+    if (ok) {
+        const int n = g.n, n_nodes = g.n_nodes;
         order.resize((size_t)n);
         std::vector<int> hs((size_t)n_nodes), he((size_t)n_nodes), hl((size_t)n_nodes), hd((size_t)n_nodes);
         std::vector<float> hb(6 * (size_t)n_nodes);
-        GB_TRY(hipMemcpyAsync(order.data(), d_order, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st));
-        GB_TRY(hipMemcpyAsync(hs.data(), t.start, (size_t)n_nodes * sizeof(int), hipMemcpyDeviceToHost, st));
-        GB_TRY(hipMemcpyAsync(he.data(), t.end, (size_t)n_nodes * sizeof(int), hipMemcpyDeviceToHost, st));
-        GB_TRY(hipMemcpyAsync(hl.data(), t.left, (size_t)n_nodes * sizeof(int), hipMemcpyDeviceToHost, st));
-        GB_TRY(hipMemcpyAsync(hd.data(), t.depth, (size_t)n_nodes * sizeof(int), hipMemcpyDeviceToHost, st));
-        GB_TRY(hipMemcpyAsync(hb.data(), t.box, 6 * (size_t)n_nodes * sizeof(float), hipMemcpyDeviceToHost, st));
-        GB_TRY(hipStreamSynchronize(st));
-        lap("download");
+        {
+            GB_TRY(hipMemcpyAsync(order.data(), g.d_order, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, g.st));
+            GB_TRY(hipMemcpyAsync(hs.data(), g.t.start, (size_t)n_nodes * sizeof(int), hipMemcpyDeviceToHost, g.st));
+            GB_TRY(hipMemcpyAsync(he.data(), g.t.end, (size_t)n_nodes * sizeof(int), hipMemcpyDeviceToHost, g.st));
+            GB_TRY(hipMemcpyAsync(hl.data(), g.t.left, (size_t)n_nodes * sizeof(int), hipMemcpyDeviceToHost, g.st));
+            GB_TRY(hipMemcpyAsync(hd.data(), g.t.depth, (size_t)n_nodes * sizeof(int), hipMemcpyDeviceToHost, g.st));
+            GB_TRY(hipMemcpyAsync(hb.data(), g.t.box, 6 * (size_t)n_nodes * sizeof(float), hipMemcpyDeviceToHost, g.st));
+            GB_TRY(hipStreamSynchronize(g.st));
+        }
+        g.lap("download");
         nodes.resize((size_t)n_nodes);
-        max_depth = 0;
         for (int i = 0; i < n_nodes; ++i) {
             RtBuildNode &b = nodes[(size_t)i];
             for (int k = 0; k < 3; ++k) { b.lo[k] = hb[6 * (size_t)i + k]; b.hi[k] = hb[6 * (size_t)i + 3 + k]; }
             b.left = hl[i]; b.right = hl[i] >= 0 ? hl[i] + 1 : -1; b.start = hs[i]; b.end = he[i]; b.depth = hd[i];
             if (hd[i] > max_depth) max_depth = hd[i];
         }
-        lap("convert");
+        g.lap("convert");
     }
 done:
-    hipFree(d_box); hipFree(d_order); hipFree(d_node_of); hipFree(d_flag); hipFree(d_scan); hipFree(d_pairL); hipFree(d_pairR); hipFree(d_bin);
-    hipFree(d_next); hipFree(d_tmp); hipFree(t.start); hipFree(t.end); hipFree(t.left); hipFree(t.depth); hipFree(t.box);
-    hipFree(lv.all); hipFree(lv.binCount); hipFree(lv.binBox); hipFree(lv.ax); hipFree(lv.split); hipFree(lv.mid); hipFree(lv.clo); hipFree(lv.chi);
-    if (st) hipStreamDestroy(st);
-    lap("free");
+    g.release();
+    return ok;
+}
+
+// Build AND flatten on the device: the scene arrays the traversal reads never exist on the host.  shape_rec: one 64-byte
+// DevPrim per shape (host), pshape: shape of every reference primitive (host).  On success the caller owns out.* (hipFree).
+bool rt_bvh_gpu_build_flatten(const float *pbox, int64_t n64, const DevPrim *shape_rec, int64_t n_shapes, const int32_t *pshape, RtGpuScene &out, std::string &err) {
+    out = RtGpuScene();
+    if (n64 <= 0) { err = "empty scene"; return false; }
+    GpuBuild g;
+    bool ok = g.build(pbox, (int)n64, err);
+    float4 *d_shape = nullptr; int *d_pshape = nullptr, *d_uniq = nullptr, *d_dev_start = nullptr, *d_leaf_ref = nullptr, *d_cnt = nullptr;
+    int2 *d_work[2] = {nullptr, nullptr};
+    if (ok) {
+        const int n = g.n, n_nodes = g.n_nodes;
+        hipStream_t st = g.st;
+        const dim3 blk(256), grid_n((n + 1 + 255) / 256), grid_nodes((n_nodes + 255) / 256);
+        int n_leaves = 0, n_leaf_prims = 0;
+        {
+            GB_TRY(dalloc(&d_shape, 4 * (size_t)n_shapes)); GB_TRY(dalloc(&d_pshape, (size_t)n));
+            GB_TRY(hipMemcpyAsync(d_shape, shape_rec, (size_t)n_shapes * sizeof(DevPrim), hipMemcpyHostToDevice, st));
+            GB_TRY(hipMemcpyAsync(d_pshape, pshape, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+            // leaves in order of their range start
+            GB_TRY(hipMemsetAsync(g.d_flag, 0, ((size_t)n + 1) * sizeof(int), st));
+            hipLaunchKernelGGL(k_mark_leaves, grid_nodes, blk, 0, st, g.t, n_nodes, g.d_flag);
+            GB_TRY(hipcub::DeviceScan::ExclusiveSum(g.d_tmp, g.tmp_bytes, g.d_flag, g.d_scan, n + 1, st));      // d_scan[start] = leaf index
+            GB_TRY(hipMemcpyAsync(&n_leaves, g.d_scan + n, sizeof(int), hipMemcpyDeviceToHost, st));
+            GB_TRY(hipStreamSynchronize(st));
+            GB_TRY(dalloc(&d_uniq, (size_t)n_leaves + 1)); GB_TRY(dalloc(&d_dev_start, (size_t)n_leaves + 1)); GB_TRY(dalloc(&d_leaf_ref, (size_t)n_nodes));
+            GB_TRY(dalloc(&d_cnt, 4));
+            GB_TRY(hipMemsetAsync(d_uniq, 0, ((size_t)n_leaves + 1) * sizeof(int), st));
+            GB_TRY(hipMemsetAsync(d_cnt, 0, 4 * sizeof(int), st));
+            hipLaunchKernelGGL(k_leaf_unique, grid_nodes, blk, 0, st, g.t, n_nodes, g.d_order, d_pshape, g.d_scan, d_uniq);
+            {   // the scan temp storage was sized for n + 1 >= n_leaves + 1 items
+                size_t need = 0;
+                GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need, d_uniq, d_dev_start, n_leaves + 1));
+                if (need > g.tmp_bytes) { hipFree(g.d_tmp); g.d_tmp = nullptr; GB_TRY(hipMalloc(&g.d_tmp, need)); g.tmp_bytes = need; }
+            }
+            GB_TRY(hipcub::DeviceScan::ExclusiveSum(g.d_tmp, g.tmp_bytes, d_uniq, d_dev_start, n_leaves + 1, st));
+            GB_TRY(hipMemcpyAsync(&n_leaf_prims, d_dev_start + n_leaves, sizeof(int), hipMemcpyDeviceToHost, st));
+            GB_TRY(hipStreamSynchronize(st));
+            GB_TRY(dalloc(&out.prims, (size_t)n_leaf_prims)); GB_TRY(dalloc(&out.leaves, (size_t)n_leaves)); GB_TRY(dalloc(&out.chain, (size_t)n_nodes));
+            hipLaunchKernelGGL(k_leaf_write, grid_nodes, blk, 0, st, g.t, n_nodes, g.d_order, d_pshape, g.d_scan, d_dev_start, d_shape,
+                               reinterpret_cast<float4 *>(out.prims), out.leaves, d_leaf_ref, d_cnt + 3);
+            hipLaunchKernelGGL(k_chain, grid_nodes, blk, 0, st, g.t, n_nodes, out.chain);
+            g.lap("leaves, records, chain");
+            // wide nodes
+            const int n_internal = (n_nodes - 1) / 2;                 // a full binary tree: every internal node has two children
+            int n_wide = 0, wide_depth = 0;
+            if (n_internal > 0) {
+                GB_TRY(dalloc(&out.nodes, (size_t)n_internal));        // at most one wide node per internal reference node
+                GB_TRY(dalloc(&d_work[0], (size_t)n_internal)); GB_TRY(dalloc(&d_work[1], (size_t)n_internal));
+                const int2 first = make_int2(0, 0);
+                const int one = 1;
+                GB_TRY(hipMemcpyAsync(d_work[0], &first, sizeof(first), hipMemcpyHostToDevice, st));
+                GB_TRY(hipMemcpyAsync(d_cnt + 0, &one, sizeof(int), hipMemcpyHostToDevice, st));      // wide node count
+                int n_work = 1, cur = 0;
+                while (n_work > 0) {
+                    ++wide_depth;
+                    GB_TRY(hipMemsetAsync(d_cnt + 1, 0, sizeof(int), st));
+                    hipLaunchKernelGGL(k_collapse, dim3((n_work + 255) / 256), blk, 0, st, g.t, d_leaf_ref, d_work[cur], n_work, d_work[cur ^ 1], d_cnt + 1, d_cnt + 0, out.nodes);
+                    GB_TRY(hipMemcpyAsync(&n_work, d_cnt + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+                    GB_TRY(hipStreamSynchronize(st));
+                    cur ^= 1;
+                }
+                GB_TRY(hipMemcpyAsync(&n_wide, d_cnt + 0, sizeof(int), hipMemcpyDeviceToHost, st));
+            }
+            int status = 0, root_ref = 0;
+            float root_box[6];
+            GB_TRY(hipMemcpyAsync(&status, d_cnt + 3, sizeof(int), hipMemcpyDeviceToHost, st));
+            GB_TRY(hipMemcpyAsync(&root_ref, d_leaf_ref, sizeof(int), hipMemcpyDeviceToHost, st));
+            GB_TRY(hipMemcpyAsync(root_box, g.t.box, sizeof(root_box), hipMemcpyDeviceToHost, st));
+            GB_TRY(hipStreamSynchronize(st));
+            GB_TRY(hipGetLastError());
+            if (status) { err = "too many BVH leaves for the packed leaf reference"; ok = false; goto done; }
+            out.n_wide = n_wide; out.n_nodes = n_nodes; out.n_leaves = n_leaves; out.n_leaf_prims = n_leaf_prims;
+            out.root = n_internal > 0 ? 0 : root_ref;
+            for (int k = 0; k < 3; ++k) { out.root_lo[k] = root_box[k]; out.root_hi[k] = root_box[3 + k]; }
+            out.max_depth = g.max_depth;
+            out.stack_bound = 3 * wide_depth + 2;
+            g.lap("wide nodes");
+        }
+    }
+done:
+    hipFree(d_shape); hipFree(d_pshape); hipFree(d_uniq); hipFree(d_dev_start); hipFree(d_leaf_ref); hipFree(d_cnt); hipFree(d_work[0]); hipFree(d_work[1]);
+    if (!ok) { hipFree(out.nodes); hipFree(out.chain); hipFree(out.leaves); hipFree(out.prims); out = RtGpuScene(); }
+    g.release();
     return ok;
 }
