@@ -53,6 +53,14 @@ def test_no_device_is_a_loud_error(rt):
         rt.Context(0)
     assert e.value.code == rt.abi.RT_ERR_NO_DEVICE
     assert "no CPU fallback" in str(e.value)
+    # the GPU BVH builder does not fall back to the host builder either
+    b = rt.SceneBuilder()
+    b.add_material()
+    b.add_triangle((0, 0, 0), (1, 0, 0), (0, 1, 0))
+    b.add_camera((0, 0, 5), (0, 0, -1), (0, 1, 0), (-1, 1, -1, 1), 1, 8, 8)
+    with pytest.raises(rt.RtError) as e:
+        rt.renderer.host_bvh(b.finish(), gpu_device=0)
+    assert e.value.code == rt.abi.RT_ERR_NO_DEVICE
 
 
 def test_host_helpers(rt):
