@@ -86,6 +86,7 @@ struct DevSceneParams {
     int32_t bvh_depth;        // depth of the reference (binary) tree
     int32_t stack_bound;      // most entries a traversal of the 4-wide tree can have on its stack
     int32_t tri_min_lanes;    // run the primitive path of the traversal once this many lanes of a wave wait in a leaf
+    int32_t refill_min_idle;  // retire + refill (or donate) once this many lanes of a wave are idle
     int32_t donate;           // 1: idle lanes of a wave take over stack entries of its long rays once the queue is empty
     int32_t has_normal_tex;   // any object with a normal texture   } select the k_shade_pre instantiation
     int32_t has_rng;          // any area light or glossy material  }

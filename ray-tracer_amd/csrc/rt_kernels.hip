@@ -263,7 +263,7 @@ __device__ __noinline__ bool chain_visit(const DevChain *chain, int node, f3 o, 
 #define CUR_NONE 0x7ffffffd      // no node left to visit (stack empty); the lane may still hold a pending leaf
 #define CUR_WAIT 0x7ffffffc      // lane finished its own traversal and waits for parts it gave away
 #define TRACE_CHUNK 64           // rays a wave reserves per atomic
-#define REFILL_MIN_IDLE 8        // retire + refill once this many lanes are idle
+#define REFILL_MIN_IDLE 24       // default of DevSceneParams::refill_min_idle: retire + refill once this many lanes are idle
 #define TRI_MIN_LANES 16         // run the primitive path once this many lanes wait in a leaf
 #define LDS_PAYLOAD 15           // dwords per lane: ip.xyz, beta, gamma of the leaf-local candidate, then of the best one, then the
                                  // rarely used lane state below
@@ -332,7 +332,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
             bool fin = has_ray && cur == CUR_DONE;
             const unsigned long long idle0 = __ballot(!has_ray || fin);
             unsigned long long parts_done = any_parts ? __ballot(fin && plane != lane) : 0ull;
-            if (__popcll(idle0) >= REFILL_MIN_IDLE || parts_done || !__any(working)) {
+            if (__popcll(idle0) >= sc.p.refill_min_idle || parts_done || !__any(working)) {
                 // 1. merge finished parts into the lanes they report to
                 while (parts_done) {
                     const int s = __ffsll((long long)parts_done) - 1;
@@ -374,7 +374,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                 }
                 const unsigned long long idle = __ballot(!has_ray);
                 const int nidle = __popcll(idle);
-                if (nidle >= REFILL_MIN_IDLE && (!exhausted || chunk_next < chunk_end)) {
+                if (nidle >= sc.p.refill_min_idle && (!exhausted || chunk_next < chunk_end)) {
                     // 3a. new rays from the wave's chunk of the queue
                     if (chunk_next >= chunk_end) {
                         int base = 0;
@@ -418,7 +418,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                         }
                     }
                     chunk_next += nidle < avail ? nidle : avail;
-                } else if (nidle >= REFILL_MIN_IDLE && sc.p.donate) {
+                } else if (nidle >= sc.p.refill_min_idle && sc.p.donate) {
                     // 3b. nothing left in the queue: split the rays still in flight
                     const bool can_give = has_ray && cur != CUR_DONE && sp > sbase;
                     const unsigned long long givers = __ballot(can_give);
