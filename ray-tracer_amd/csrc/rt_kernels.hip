@@ -400,8 +400,10 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                             // Q2: the hit parameter is (ip.x - o.x)/d.x; with d.x == 0 (or NaN) no hit is ever accepted.
                             bool alive = !no_scene && (d.x != 0.0f);
                             if (COUNT) ++dbg.boxes;
-                            if (alive) alive = slab_exact(ld3(sc.p.root_min), ld3(sc.p.root_max), o, d);
-                            // a root that is itself a leaf was just decided exactly; below it every leaf is decided at its parent
+                            // The reference tests the root box first.  Below a wide root that test is implied: a leaf is visited only
+                            // on a decided hit of its own box (which implies every ancestor's exact test, the root's included) or
+                            // after the exact chain walk, which ends at the root.  Only a root that is itself a leaf needs it here.
+                            if (alive && sc.p.root < 0) alive = slab_exact(ld3(sc.p.root_min), ld3(sc.p.root_max), o, d);
                             if (alive) {
                                 r = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                                 // a zero / denormal-range direction component (inf and NaN quotients): every fast test undecided
