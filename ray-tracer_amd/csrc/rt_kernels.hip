@@ -226,7 +226,11 @@ __device__ __forceinline__ int slab_fast(float bminx, float bminy, float bminz, 
 // undecided (a ray grazing the leaf box within 1e-6 relative — every hit on a flat, axis-aligned leaf box is one — or a ray
 // with a zero direction component).  Walks up: an undecided box gets the exact test; the first box the fast test decides
 // ends the walk, because a decided hit implies that every box above it passes too (nesting).
-__device__ __noinline__ bool chain_visit(const DevChain *chain, int node, f3 o, f3 d, f3 r, float amb) {
+__device__ __noinline__ bool chain_visit(const DevChain *chain, int node, bool leaf, f3 o, f3 d, f3 r, float amb) {
+    if (!leaf) {                      // internal child of a zero-component ray: the reference's test of that one box
+        const DevChain c = chain[node];
+        return slab_exact(ld3(c.lo), ld3(c.hi), o, d);
+    }
     const f3 zero = mk3(0, 0, 0);
     while (node >= 0) {
         const DevChain c = chain[node];
@@ -399,6 +403,10 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                             plane = lane; bound = FLT_MAX;
                             // Q2: the hit parameter is (ip.x - o.x)/d.x; with d.x == 0 (or NaN) no hit is ever accepted.
                             bool alive = !no_scene && (d.x != 0.0f);
+                            // A NaN anywhere in the ray makes every box test of the reference pass (its comparisons are all
+                            // false) and every primitive test fail (t >= -eps is false for NaN): the reference walks the WHOLE
+                            // tree and finds nothing.  Same answer at once.
+                            alive = alive && (o.x == o.x) && (o.y == o.y) && (o.z == o.z) && (d.x == d.x) && (d.y == d.y) && (d.z == d.z);
                             if (COUNT) ++dbg.boxes;
                             // The reference tests the root box first.  Below a wide root that test is implied: a leaf is visited only
                             // on a decided hit of its own box (which implies every ancestor's exact test, the root's included) or
@@ -511,8 +519,11 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                 int c = slab_fast(mnx[i], mny[i], mnz[i], mxx[i], mxy[i], mxz[i], o, r, marg, amb, tn, lb);
                 if (c == 2) lb = -FLT_MAX;                        // undecided: no pruning either
                 if (cref[i] == DEV_REF_EMPTY || lb > bound) c = 0;
-                // an undecided INTERNAL child is entered (boxes nest: that is conservative); an undecided LEAF is decided exactly
-                if (c == 2) { if (cref[i] < 0) need_chain = true; else c = 1; }
+                // An undecided LEAF is decided exactly by the chain walk.  An undecided INTERNAL child of an ordinary ray (grazing
+                // its box) is simply entered: boxes nest, so that is conservative and cheap.  A ray with a zero direction component
+                // has EVERY test undecided and would walk the whole tree that way (measured: 3 s per 4K frame of config 5), so
+                // for it the internal child gets the reference's exact test of its own box.
+                if (c == 2) { if (cref[i] < 0 || !(amb < 1.0f)) need_chain = true; else c = 1; }
                 cls[i] = c;
                 key[i] = fminf(fmaxf(tn, 0.0f), FLT_MAX);         // NaN -> 0
             }
@@ -522,7 +533,8 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                 const int cch[4] = {__float_as_int(q7.x), __float_as_int(q7.y), __float_as_int(q7.z), __float_as_int(q7.w)};
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (cls[i] == 2) cls[i] = chain_visit(sc.chain, cch[i], o, mk3(dirx, pay[PAY_DY * TRACE_BLOCK], pay[PAY_DZ * TRACE_BLOCK]), r, amb) ? 1 : 0;
+                    if (cls[i] == 2)
+                        cls[i] = chain_visit(sc.chain, cch[i], cref[i] < 0, o, mk3(dirx, pay[PAY_DY * TRACE_BLOCK], pay[PAY_DZ * TRACE_BLOCK]), r, amb) ? 1 : 0;
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) if (cls[i] == 0) key[i] = __int_as_float(0x7f800000);      // +inf: not taken, sorts last

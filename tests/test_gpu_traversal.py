@@ -105,6 +105,31 @@ def test_donation_on_long_rays(rt, orc, gpu_ctx):
     assert (c["shape"] >= 0).sum() > n // 10
 
 
+def test_zero_component_rays_do_not_walk_the_tree(rt, orc, gpu_ctx):
+    """Rays with an exactly zero direction component make every reciprocal box test undecidable; internal boxes then take
+    the reference's exact test instead of being entered.  Results equal the oracle's and the node visits stay far below
+    "every ray visits every node" (found at 4K on the config-5 scene: axis-parallel primary columns cost seconds)."""
+    soup = synth.dragon_standin_scene(60000, 64, 48)
+    gpu_ctx.upload(soup)
+    n_nodes = gpu_ctx.bvh_info().n_wide_nodes
+    rng = np.random.RandomState(5)
+    n = 4096
+    r = np.zeros(n, abi.ray_dtype)
+    o = (rng.rand(n, 3) - 0.5) * np.array([10.0, 4.0, 10.0]) + np.array([0.0, 4.0, 0.0])
+    d = rng.randn(n, 3)
+    d[np.arange(n), 1 + rng.randint(2, size=n)] = 0.0          # y or z exactly zero (x == 0 rays hit nothing in the reference)
+    d[: n // 4, 1] = 0.0
+    d[: n // 8, 2] = 0.0                                        # some rays along +-x only
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    r["origin"], r["direction"] = o.astype(np.float32), d.astype(np.float32)
+    g, st = gpu_ctx.intersect(r, stats=True)
+    c = orc.OracleScene(soup).intersect(r)
+    assert np.array_equal(g["shape"], c["shape"])
+    assert np.array_equal(g["t"].view(np.uint32), c["t"].view(np.uint32))
+    assert (c["shape"] >= 0).sum() > 0
+    assert n_nodes > 10000 and st.node_visits < n * n_nodes // 20
+
+
 @pytest.mark.parametrize("name", ["cornellbox", "bunny", "scienceTree", "cornellbox_boxes_dynamic", "spheres", "metal_glass_plates"])
 def test_gpu_bvh_build_equals_host_build(rt, scene_path, name):
     """The GPU builder (level-synchronous, parallel partition) must produce the reference's tree exactly: same leaves in the
