@@ -272,6 +272,45 @@ int rt_perlin_tables(int n_tables, int32_t *out);
 /* ObtainColorFromUnclampedVector (src/DefaultRenderer.cpp:18-27): float RGB -> 8-bit, n = pixel count. */
 int rt_resolve_8bit(const float *hdr_rgb, int64_t n_pixels, uint8_t *out_rgb);
 
+/* ---- what the reference does with the finished frame, on the device ---------------------- */
+
+enum { RT_IMG_RGB8 = 0,      /* the reference's Image contents: ny*nx*3 unsigned chars                            */
+       RT_IMG_PPM_P3 = 1,    /* the file Image::SaveImageAsPPM writes, byte for byte                                */
+       RT_IMG_PPM_P6 = 2 };  /* binary PPM of the same 8-bit image (not in the reference; 4-5x smaller)             */
+
+/* Upper bound of the bytes rt_image_encode produces for an nx*ny frame in `format` (0 for bad arguments). */
+size_t rt_image_encode_bound(int nx, int ny, int format);
+
+/* Replaces ObtainColorFromUnclampedVector (src/DefaultRenderer.cpp:18-27: >255 -> 255, float -> unsigned char) and
+ * Image::SaveImageAsPPM (src/Image.cpp:54-77: "P3\n%d %d\n255\n", then "%d " per channel and "\n" per row) for a
+ * float frame as rt_render produces it.  hdr_rgb is a device pointer when hdr_on_device != 0.  The encoded bytes go to
+ * the HOST buffer out_host (capacity out_capacity); *out_bytes receives their number; *ms_kernels (optional) the HIP
+ * event time of the kernels. */
+int rt_image_encode(rt_ctx *ctx, const float *hdr_rgb, int nx, int ny, int hdr_on_device, int format, void *out_host,
+                    size_t out_capacity, size_t *out_bytes, double *ms_kernels);
+
+typedef struct rt_tonemap_opts {
+    uint32_t abi_version;
+    float key;                /* <TMOOptions> first number  (TonemapSettings::imageBurnKey)                          */
+    float burn_percent;       /* <TMOOptions> second number (TonemapSettings::saturationPercentage)                  */
+    float saturation;         /* <Saturation>                                                                        */
+    float gamma;              /* <Gamma>: parsed, never used by the reference                                        */
+    int32_t input_8bit;       /* 1: clamp the frame to 8 bit first, as the reference does (it tone-maps its Image of
+                                 Colors, Q20); 0: tone-map the float radiance                                        */
+    int32_t in_on_device;     /* hdr_rgb is a device pointer                                                         */
+    int32_t out_on_device;    /* out_rgb is a device pointer                                                         */
+} rt_tonemap_opts;            /* 32 bytes */
+
+/* Replaces Tonemapper::Tonemap / DefaultTonemapStrategy::ComputeTonemappedValues (src/Tonemapper.cpp:27-32,
+ * src/DefaultTonemapStrategy.cpp:15-114): luminance per pixel, exp(mean log luminance), luminance white from the sorted
+ * luminances at the burn percentile, Reinhard curve with burn, saturation exponent.  out_rgb: [ny*nx*3] float, the array
+ * the reference hands to SaveEXR.  out_params (optional, host): [0] average luminance, [1] luminance white.
+ * The reference's function is undefined behaviour as written (FillLuminanceVectorAndRecordSum returns no value, rows are
+ * bounded by the image WIDTH, Image.h:60-63, and burn_percent == 0 indexes one past the end); implemented here is what
+ * the code computes when the sum is returned, rows are bounded by the height and the index is clamped. */
+int rt_tonemap(rt_ctx *ctx, const float *hdr_rgb, int nx, int ny, const rt_tonemap_opts *opts, float *out_rgb,
+               float *out_params, double *ms_kernels);
+
 /* Host-only view of the BVH that rt_scene_upload would build (reference topology, BVHTree.cpp:39-153), so that tests
  * can compare it with an independent build without a GPU.  Leaves are listed in left-to-right DFS order.
  *   leaf_start_end      [2*n_leaves]  range of each leaf in the reference's re-ordered primitive array
@@ -292,7 +331,7 @@ int rt_host_bvh_leaves(const rt_host_bvh *bvh, int64_t *leaf_start_end, int32_t 
 void rt_host_bvh_free(rt_host_bvh *bvh);
 
 /* sizeof() of the ABI structs, in header order (0 rt_material, 1 rt_light, 2 rt_texture, 3 rt_object, 4 rt_scene_desc,
- * 5 rt_camera_desc, 6 rt_render_opts, 7 rt_stats, 8 rt_ray, 9 rt_hit, 10 rt_bvh_info); -1 for anything else. */
+ * 5 rt_camera_desc, 6 rt_render_opts, 7 rt_stats, 8 rt_ray, 9 rt_hit, 10 rt_bvh_info, 11 rt_tonemap_opts); -1 for anything else. */
 int rt_abi_sizeof(int which);
 
 uint32_t rt_abi_version(void);

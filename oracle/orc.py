@@ -42,6 +42,9 @@ def lib():
         L.orc_inverse4.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_box_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_camera_ray.argtypes = [C.POINTER(abi.CameraDesc), C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_tonemap.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.orc_ppm_p3.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.orc_ppm_p3.restype = C.c_size_t
         L.orc_abi_version.restype = C.c_uint32
         assert L.orc_abi_version() == abi.RT_ABI_VERSION
         _LIB = L
@@ -115,3 +118,30 @@ def camera_ray(cd, row, col, sample=0, seed=0):
     t = np.zeros(1, np.float32)
     lib().orc_camera_ray(C.byref(cd), row, col, sample, seed, o.ctypes.data, d.ctypes.data, t.ctypes.data)
     return o, d, float(t[0])
+
+
+def resolve_8bit(hdr):
+    """ObtainColorFromUnclampedVector (DefaultRenderer.cpp:18-27): > 255 -> 255, then truncation to unsigned char (negative
+    inputs, undefined in the reference, give 0)."""
+    v = np.asarray(hdr, np.float32)
+    return np.where(v > 255.0, 255, np.trunc(np.maximum(v, 0.0))).astype(np.uint8)
+
+
+def ppm_p3(rgb8):
+    """Image::SaveImageAsPPM (Image.cpp:54-77) as bytes."""
+    rgb8 = np.ascontiguousarray(rgb8, np.uint8)
+    h, w, _ = rgb8.shape
+    out = np.zeros(12 * h * w + h + 64, np.uint8)
+    n = lib().orc_ppm_p3(rgb8.ctypes.data, w, h, out.ctypes.data, out.size)
+    return out[:n].tobytes()
+
+
+def tonemap(channels, key, burn_percent, saturation):
+    """DefaultTonemapStrategy on float channel values [ny, nx, 3] (8-bit values as floats for the reference's path)."""
+    v = np.ascontiguousarray(channels, np.float32)
+    out = np.zeros(v.shape, np.float32)
+    params = np.zeros(2, np.float32)
+    rc = lib().orc_tonemap(v.ctypes.data, v.shape[1], v.shape[0], key, burn_percent, saturation, out.ctypes.data, params.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("orc_tonemap rc=%d" % rc)
+    return out, params

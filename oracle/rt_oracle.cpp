@@ -1428,6 +1428,64 @@ int orc_intersect_batch(void *h, const rt_ray *rays, size_t n, rt_hit *hits) {
     return 0;
 }
 
+// Tonemapper::Tonemap with the default strategy (DefaultTonemapStrategy.cpp:15-114, DefaultTonemapStrategy.h:43-46) on a
+// frame whose channel values are given as floats (the reference's are 8-bit Colors converted to float).  The reference's
+// code is undefined behaviour as written: FillLuminanceVectorAndRecordSum (:48-62) has no return statement, both loops
+// bound the ROW index by GetImageHeight() which returns the width (Image.h:60-63), and a burn percentage of 0 reads one
+// element past the sorted luminances (:106).  Restated here: the value the function accumulates is the value used, rows
+// run over the height, the index is clamped to the last element.  PARITY UNPINNED (no reference output exists).
+int orc_tonemap(const float *rgb, int nx, int ny, float key, float burnPercent, float saturation, float *out, float *params) {
+    if (!rgb || !out || nx <= 0 || ny <= 0) return RT_ERR_INVALID;
+    const size_t n = (size_t)nx * (size_t)ny;
+    std::vector<float> luminances;
+    luminances.reserve(n);
+    float luminanceSum = 0.0f;
+    for (size_t i = 0; i < n; ++i) {                                   // RecordPixelLuminance :64-71
+        float luminance = 0.27f * rgb[3 * i] + 0.67f * rgb[3 * i + 1] + 0.06f * rgb[3 * i + 2];
+        luminances.push_back(luminance);
+        luminanceSum += log(luminance + 0.00001f);                     // ::log(double); float += double
+    }
+    std::make_heap(luminances.begin(), luminances.end());               // HeapifyLuminanceVector :73-77
+    std::sort_heap(luminances.begin(), luminances.end());
+    double pos = round(luminances.size() * (100.f - burnPercent) / 100.f);   // ComputeLuminanceWhite :104-107
+    size_t idx = pos >= 0.0 ? (size_t)pos : 0;
+    if (idx > n - 1) idx = n - 1;
+    const float luminanceWhite = luminances[idx] / luminances.back();
+    luminanceSum /= (int)n;                                            // SetupGeneralAttributes :44-45
+    const float averageLuminance = exp(luminanceSum);
+    if (params) { params[0] = averageLuminance; params[1] = luminanceWhite; }
+    for (size_t i = 0; i < n; ++i) {                                   // ComputeTonemappedPixelColor :79-102
+        const float r = rgb[3 * i], g = rgb[3 * i + 1], b = rgb[3 * i + 2];
+        float luminance = 0.27f * r + 0.67f * g + 0.06f * b;
+        float regulatedLuminance = luminance * key / averageLuminance;
+        float resultingLuminance = (regulatedLuminance * (1 + (regulatedLuminance / (luminanceWhite * luminanceWhite)))) / (1 + regulatedLuminance);
+        out[3 * i] = std::pow(r / luminance, saturation) * resultingLuminance;
+        out[3 * i + 1] = std::pow(g / luminance, saturation) * resultingLuminance;
+        out[3 * i + 2] = std::pow(b / luminance, saturation) * resultingLuminance;
+    }
+    return 0;
+}
+
+// Image::SaveImageAsPPM (Image.cpp:54-77) into memory: the same printf conversions, sprintf instead of fprintf.
+// Returns the number of bytes the file has (writes at most cap of them).
+size_t orc_ppm_p3(const uint8_t *rgb, int nx, int ny, char *out, size_t cap) {
+    std::vector<char> line((size_t)nx * 12 + 64);
+    size_t total = 0;
+    auto emit = [&](const char *p, size_t n) { if (total < cap) std::memcpy(out + total, p, std::min(n, cap - total)); total += n; };
+    int n = std::sprintf(line.data(), "P3\n");
+    n += std::sprintf(line.data() + n, "%d %d\n", nx, ny);
+    n += std::sprintf(line.data() + n, "255\n");
+    emit(line.data(), (size_t)n);
+    for (int y = 0; y < ny; y++) {
+        int k = 0;
+        for (int x = 0; x < nx; x++)
+            for (int c = 0; c < 3; ++c) k += std::sprintf(line.data() + k, "%d ", rgb[((size_t)y * nx + x) * 3 + c]);
+        k += std::sprintf(line.data() + k, "\n");
+        emit(line.data(), (size_t)k);
+    }
+    return total;
+}
+
 // KAT hooks
 void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { orc::Philox4x32(ctr, key, out); }
 float orc_perlin(const rt_texture *tx, float x, float y, float z) { return orc::PerlinValue(*tx, x, y, z); }

@@ -96,6 +96,14 @@ class Stats(C.Structure):
                 "trace_rays": int(self.trace_rays), "ms_trace_busy": self.ms_trace_busy}
 
 
+RT_IMG_RGB8, RT_IMG_PPM_P3, RT_IMG_PPM_P6 = 0, 1, 2
+
+
+class TonemapOpts(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("key", C.c_float), ("burn_percent", C.c_float), ("saturation", C.c_float),
+                ("gamma", C.c_float), ("input_8bit", C.c_int32), ("in_on_device", C.c_int32), ("out_on_device", C.c_int32)]
+
+
 class BvhInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_int64), ("n_leaves", C.c_int64), ("max_depth", C.c_int32), ("n_wide_nodes", C.c_int32),
                 ("n_leaf_prims", C.c_int64)]

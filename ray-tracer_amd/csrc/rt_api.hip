@@ -158,6 +158,11 @@ struct rt_ctx {
     DevArray<rt_ray> d_rays;
     DevArray<rt_hit> d_hits;
     int overflow_depth = 0;
+    // frame post-processing (rt_image_encode, rt_tonemap)
+    DevArray<float> d_img_in, d_tm_lum, d_tm_sorted, d_tm_out, d_tm_params;
+    DevArray<uint8_t> d_img8, d_img_text, d_img_tmp;
+    DevArray<unsigned long long> d_img_len, d_img_off;
+    DevArray<double> d_tm_partial;
 };
 
 static void release_all(rt_ctx *c) {
@@ -169,6 +174,8 @@ static void release_all(rt_ctx *c) {
     c->d_pixels.release(); c->d_overflow.release();
     c->d_counts.release(); c->d_kind.release(); c->d_counters.release(); c->d_hdr.release(); c->d_pid.release(); c->d_pt.release();
     c->d_rays.release(); c->d_hits.release();
+    c->d_img_in.release(); c->d_tm_lum.release(); c->d_tm_sorted.release(); c->d_tm_out.release(); c->d_tm_params.release();
+    c->d_img8.release(); c->d_img_text.release(); c->d_img_tmp.release(); c->d_img_len.release(); c->d_img_off.release(); c->d_tm_partial.release();
 }
 
 extern "C" {
@@ -663,6 +670,134 @@ int rt_intersect_batch(rt_ctx *c, const rt_ray *rays, size_t n, rt_hit *hits, in
     return RT_OK;
 }
 
+// ---- frame post-processing ---------------------------------------------------------------------------
+static int ppm_header(char *buf, size_t cap, int format, int nx, int ny) {
+    return std::snprintf(buf, cap, "P%d\n%d %d\n255\n", format == RT_IMG_PPM_P3 ? 3 : 6, nx, ny);   // Image.cpp:59-61
+}
+
+size_t rt_image_encode_bound(int nx, int ny, int format) {
+    if (nx <= 0 || ny <= 0) return 0;
+    const size_t npx = (size_t)nx * (size_t)ny;
+    switch (format) {
+    case RT_IMG_RGB8: return 3 * npx;
+    case RT_IMG_PPM_P6: return 3 * npx + 40;
+    case RT_IMG_PPM_P3: return 12 * npx + (size_t)ny + 40;
+    default: return 0;
+    }
+}
+
+namespace {
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    bool on = false;
+    hipError_t start(bool want, hipStream_t s) {
+        on = want;
+        if (!on) return hipSuccess;
+        hipError_t e;
+        if ((e = hipEventCreate(&a)) != hipSuccess) return e;
+        if ((e = hipEventCreate(&b)) != hipSuccess) return e;
+        return hipEventRecord(a, s);
+    }
+    hipError_t stop(hipStream_t s) { return on ? hipEventRecord(b, s) : hipSuccess; }
+    double ms() const { float m = 0; if (on) hipEventElapsedTime(&m, a, b); return m; }
+    ~EventPair() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); }
+};
+}  // namespace
+
+int rt_image_encode(rt_ctx *c, const float *hdr_rgb, int nx, int ny, int hdr_on_device, int format, void *out_host, size_t out_capacity,
+                    size_t *out_bytes, double *ms_kernels) {
+    if (!c) return RT_ERR_INVALID;
+    if (out_bytes) *out_bytes = 0;
+    if (!hdr_rgb || !out_host || nx <= 0 || ny <= 0 || (format != RT_IMG_RGB8 && format != RT_IMG_PPM_P3 && format != RT_IMG_PPM_P6)) {
+        c->error = "rt_image_encode: bad argument"; return RT_ERR_INVALID;
+    }
+    const int64_t npx = (int64_t)nx * ny;
+    if (npx > 0x7fffffff / 4) { c->error = "rt_image_encode: frame larger than 2^29 pixels"; return RT_ERR_TOO_LARGE; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const float *d_hdr = hdr_rgb;
+    if (!hdr_on_device) {
+        HIP_TRY(c, c->d_img_in.ensure((size_t)npx * 3));
+        HIP_TRY(c, hipMemcpyAsync(c->d_img_in.p, hdr_rgb, (size_t)npx * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+        d_hdr = c->d_img_in.p;
+    }
+    HIP_TRY(c, c->d_img8.ensure((size_t)npx * 3));
+    char header[48];
+    const int hlen = format == RT_IMG_RGB8 ? 0 : ppm_header(header, sizeof(header), format, nx, ny);
+    uint8_t *out = static_cast<uint8_t *>(out_host);
+    EventPair ev;
+    if (format != RT_IMG_PPM_P3) {
+        if (out_capacity < (size_t)hlen + (size_t)npx * 3) { c->error = "rt_image_encode: output buffer too small"; return RT_ERR_INVALID; }
+        HIP_TRY(c, ev.start(ms_kernels != nullptr, s));
+        HIP_TRY(c, rt_img_resolve8(s, d_hdr, npx * 3, c->d_img8.p));
+        HIP_TRY(c, ev.stop(s));
+        std::memcpy(out, header, (size_t)hlen);
+        HIP_TRY(c, hipMemcpyAsync(out + hlen, c->d_img8.p, (size_t)npx * 3, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (out_bytes) *out_bytes = (size_t)hlen + (size_t)npx * 3;
+        if (ms_kernels) *ms_kernels = ev.ms();
+        return RT_OK;
+    }
+    const int64_t nb = rt_img_p3_blocks(npx);
+    size_t scan_bytes = 0;
+    HIP_TRY(c, rt_img_p3_scan_bytes(npx, &scan_bytes));
+    HIP_TRY(c, c->d_img_tmp.ensure(scan_bytes + 16));
+    HIP_TRY(c, c->d_img_len.ensure((size_t)nb + 1));
+    HIP_TRY(c, c->d_img_off.ensure((size_t)nb + 1));
+    HIP_TRY(c, c->d_img_text.ensure(12 * (size_t)npx + (size_t)ny + 16));
+    HIP_TRY(c, ev.start(ms_kernels != nullptr, s));
+    HIP_TRY(c, rt_img_resolve8(s, d_hdr, npx * 3, c->d_img8.p));
+    HIP_TRY(c, rt_img_p3_measure(s, c->d_img8.p, npx, nx, c->d_img_len.p, c->d_img_off.p, c->d_img_tmp.p, scan_bytes));
+    HIP_TRY(c, rt_img_p3_write(s, c->d_img8.p, npx, nx, c->d_img_off.p, c->d_img_text.p));
+    HIP_TRY(c, ev.stop(s));
+    unsigned long long body = 0;
+    HIP_TRY(c, hipMemcpyAsync(&body, c->d_img_off.p + nb, sizeof(body), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (out_bytes) *out_bytes = (size_t)hlen + (size_t)body;
+    if (out_capacity < (size_t)hlen + (size_t)body) { c->error = "rt_image_encode: output buffer too small (see rt_image_encode_bound)"; return RT_ERR_INVALID; }
+    std::memcpy(out, header, (size_t)hlen);
+    HIP_TRY(c, hipMemcpyAsync(out + hlen, c->d_img_text.p, (size_t)body, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (ms_kernels) *ms_kernels = ev.ms();
+    return RT_OK;
+}
+
+int rt_tonemap(rt_ctx *c, const float *hdr_rgb, int nx, int ny, const rt_tonemap_opts *o, float *out_rgb, float *out_params, double *ms_kernels) {
+    if (!c) return RT_ERR_INVALID;
+    if (!o || o->abi_version != RT_ABI_VERSION) { c->error = "rt_tonemap: abi_version mismatch"; return RT_ERR_ABI; }
+    if (!hdr_rgb || !out_rgb || nx <= 0 || ny <= 0) { c->error = "rt_tonemap: bad argument"; return RT_ERR_INVALID; }
+    const int64_t npx = (int64_t)nx * ny;
+    if (npx > 0x7fffffff / 4) { c->error = "rt_tonemap: frame larger than 2^29 pixels"; return RT_ERR_TOO_LARGE; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const float *d_hdr = hdr_rgb;
+    if (!o->in_on_device) {
+        HIP_TRY(c, c->d_img_in.ensure((size_t)npx * 3));
+        HIP_TRY(c, hipMemcpyAsync(c->d_img_in.p, hdr_rgb, (size_t)npx * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+        d_hdr = c->d_img_in.p;
+    }
+    float *d_out = out_rgb;
+    if (!o->out_on_device) { HIP_TRY(c, c->d_tm_out.ensure((size_t)npx * 3)); d_out = c->d_tm_out.p; }
+    size_t sort_bytes = 0;
+    HIP_TRY(c, rt_img_sort_bytes(npx, &sort_bytes));
+    HIP_TRY(c, c->d_img_tmp.ensure(sort_bytes + 16));
+    HIP_TRY(c, c->d_tm_lum.ensure((size_t)npx)); HIP_TRY(c, c->d_tm_sorted.ensure((size_t)npx));
+    HIP_TRY(c, c->d_tm_partial.ensure((size_t)rt_img_p3_blocks(npx))); HIP_TRY(c, c->d_tm_params.ensure(2));
+    if (o->input_8bit) HIP_TRY(c, c->d_img8.ensure((size_t)npx * 3));
+    EventPair ev;
+    HIP_TRY(c, ev.start(ms_kernels != nullptr, s));
+    const void *src = d_hdr;
+    if (o->input_8bit) { HIP_TRY(c, rt_img_resolve8(s, d_hdr, npx * 3, c->d_img8.p)); src = c->d_img8.p; }   // the reference tone-maps its 8-bit Image (Q20)
+    HIP_TRY(c, rt_img_tonemap(s, src, o->input_8bit ? 1 : 0, npx, o->key, o->burn_percent, o->saturation, c->d_tm_lum.p, c->d_tm_sorted.p, c->d_tm_partial.p,
+                              c->d_tm_params.p, c->d_img_tmp.p, sort_bytes, d_out));
+    HIP_TRY(c, ev.stop(s));
+    if (!o->out_on_device) HIP_TRY(c, hipMemcpyAsync(out_rgb, d_out, (size_t)npx * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (out_params) HIP_TRY(c, hipMemcpyAsync(out_params, c->d_tm_params.p, 2 * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (ms_kernels) *ms_kernels = ev.ms();
+    return RT_OK;
+}
+
 // ---- host-only BVH view for tests (no GPU needed) ------------------------------------------------------
 struct rt_host_bvh { HostScene hs; std::string error; };
 
@@ -713,6 +848,7 @@ int rt_abi_sizeof(int which) {
     case 8: return (int)sizeof(rt_ray);
     case 9: return (int)sizeof(rt_hit);
     case 10: return (int)sizeof(rt_bvh_info);
+    case 11: return (int)sizeof(rt_tonemap_opts);
     default: return -1;
     }
 }

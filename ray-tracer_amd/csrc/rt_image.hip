@@ -1,0 +1,215 @@
+// rt_image.hip — what the reference does with a finished frame, on the device:
+//   * ObtainColorFromUnclampedVector (reference src/DefaultRenderer.cpp:18-27): float radiance -> 8-bit Color
+//   * Image::SaveImageAsPPM (src/Image.cpp:54-77): the P3 text, byte for byte what the fprintf loop produces
+//   * DefaultTonemapStrategy (src/DefaultTonemapStrategy.cpp:15-114): photographic tone mapping of the frame
+// All of it is streaming, HBM-bound byte/float work: one pass per step, coalesced reads, text staged through LDS so
+// that the variable-length output leaves the block as aligned dwords.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cstdint>
+
+#include "rt_wavefront.h"
+
+namespace {
+
+constexpr int IMG_BLOCK = 256;
+constexpr int P3_MAX_PIXEL = 13;            // "255 255 255 " + '\n'
+
+// ">255 -> 255", then the float -> unsigned char conversion (truncation).  Negative and NaN inputs are undefined
+// behaviour in the reference; 0 here (the same choice as the host helper rt_resolve_8bit).
+__device__ __forceinline__ unsigned resolve8(float v) { return v > 255.0f ? 255u : (v > 0.0f ? (unsigned)v : 0u); }
+
+__global__ __launch_bounds__(IMG_BLOCK) void k_resolve8_vec(const float4 *hdr, int64_t n4, uint32_t *out) {
+    const int64_t i = (int64_t)blockIdx.x * IMG_BLOCK + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = hdr[i];
+    out[i] = resolve8(v.x) | (resolve8(v.y) << 8) | (resolve8(v.z) << 16) | (resolve8(v.w) << 24);
+}
+
+__global__ __launch_bounds__(IMG_BLOCK) void k_resolve8(const float *hdr, int64_t first, int64_t n, uint8_t *out) {
+    const int64_t i = first + (int64_t)blockIdx.x * IMG_BLOCK + threadIdx.x;
+    if (i < n) out[i] = (uint8_t)resolve8(hdr[i]);
+}
+
+// ---- P3 text ------------------------------------------------------------------------------------------
+// fprintf("%d ", channel) for the three channels of every pixel, fprintf("\n") after every row.
+__device__ __forceinline__ int p3_len(unsigned v) { return 2 + (v >= 10u) + (v >= 100u); }
+
+__device__ __forceinline__ uint8_t *p3_put(uint8_t *p, unsigned v) {
+    const unsigned h = v / 100u, t = (v / 10u) % 10u, o = v % 10u;
+    if (v >= 100u) *p++ = (uint8_t)('0' + h);
+    if (v >= 10u) *p++ = (uint8_t)('0' + t);
+    *p++ = (uint8_t)('0' + o);
+    *p++ = ' ';
+    return p;
+}
+
+__device__ __forceinline__ int p3_pixel(const uint8_t *rgb, unsigned i, unsigned npx, unsigned nx, unsigned v[3], bool &eol) {
+    eol = false;
+    if (i >= npx) return 0;
+    v[0] = rgb[3ull * i]; v[1] = rgb[3ull * i + 1]; v[2] = rgb[3ull * i + 2];
+    eol = (i % nx) == nx - 1;
+    return p3_len(v[0]) + p3_len(v[1]) + p3_len(v[2]) + (eol ? 1 : 0);
+}
+
+__global__ __launch_bounds__(IMG_BLOCK) void k_p3_len(const uint8_t *rgb, unsigned npx, unsigned nx, unsigned long long *block_len) {
+    using Reduce = hipcub::BlockReduce<int, IMG_BLOCK>;
+    __shared__ typename Reduce::TempStorage tmp;
+    unsigned v[3]; bool eol;
+    const int len = p3_pixel(rgb, blockIdx.x * IMG_BLOCK + threadIdx.x, npx, nx, v, eol);
+    const int total = Reduce(tmp).Sum(len);
+    if (threadIdx.x == 0) block_len[blockIdx.x] = (unsigned long long)total;
+}
+
+__global__ __launch_bounds__(IMG_BLOCK) void k_p3_write(const uint8_t *rgb, unsigned npx, unsigned nx, const unsigned long long *block_off, uint8_t *out) {
+    using Scan = hipcub::BlockScan<int, IMG_BLOCK>;
+    __shared__ typename Scan::TempStorage tmp;
+    __shared__ uint32_t s_words[(IMG_BLOCK * P3_MAX_PIXEL + 8) / 4 + 1];
+    uint8_t *s = reinterpret_cast<uint8_t *>(s_words);
+    unsigned v[3] = {0, 0, 0}; bool eol;
+    const int len = p3_pixel(rgb, blockIdx.x * IMG_BLOCK + threadIdx.x, npx, nx, v, eol);
+    int off, total;
+    Scan(tmp).ExclusiveSum(len, off, total);
+    uint8_t *dst = out + block_off[blockIdx.x];
+    const int a = (int)(reinterpret_cast<uintptr_t>(dst) & 3u);       // stage at the same offset inside a dword as in memory
+    if (len) {
+        uint8_t *p = s + a + off;
+        p = p3_put(p, v[0]); p = p3_put(p, v[1]); p = p3_put(p, v[2]);
+        if (eol) *p = '\n';
+    }
+    __syncthreads();
+    uint32_t *gw = reinterpret_cast<uint32_t *>(dst - a);
+    const int end = a + total, nwords = (end + 3) >> 2;
+    for (int w = threadIdx.x; w < nwords; w += IMG_BLOCK) {
+        const int b0 = 4 * w, b1 = b0 + 4;
+        if (b0 >= a && b1 <= end) gw[w] = s_words[w];
+        else                                                          // first / last partial dword: neighbours own the other bytes
+            for (int b = (b0 > a ? b0 : a); b < (b1 < end ? b1 : end); ++b) reinterpret_cast<uint8_t *>(gw)[b] = s[b];
+    }
+}
+
+// ---- tone mapping ---------------------------------------------------------------------------------------
+// ComputeLuminance (DefaultTonemapStrategy.h:43-46); channels are 8-bit Colors converted to float in the reference.
+__device__ __forceinline__ float tm_lum(float r, float g, float b) { return 0.27f * r + 0.67f * g + 0.06f * b; }
+
+template <bool FROM8>
+__device__ __forceinline__ void tm_load(const void *src, int64_t i, float &r, float &g, float &b) {
+    if (FROM8) { const uint8_t *p = static_cast<const uint8_t *>(src) + 3 * i; r = (float)p[0]; g = (float)p[1]; b = (float)p[2]; }
+    else { const float *p = static_cast<const float *>(src) + 3 * i; r = p[0]; g = p[1]; b = p[2]; }
+}
+
+// RecordPixelLuminance (:64-71): the luminance of every pixel and log(luminance + 0.00001f) in double (the unqualified
+// `log` there is ::log(double)); partial sums per block, in a fixed order.
+template <bool FROM8>
+__global__ __launch_bounds__(IMG_BLOCK) void k_tm_lum(const void *src, int64_t npx, float *lum, double *partial) {
+    using Reduce = hipcub::BlockReduce<double, IMG_BLOCK>;
+    __shared__ typename Reduce::TempStorage tmp;
+    const int64_t i = (int64_t)blockIdx.x * IMG_BLOCK + threadIdx.x;
+    double lg = 0.0;
+    if (i < npx) {
+        float r, g, b;
+        tm_load<FROM8>(src, i, r, g, b);
+        const float l = tm_lum(r, g, b);
+        lum[i] = l;
+        lg = log((double)(l + 0.00001f));
+    }
+    const double sum = Reduce(tmp).Sum(lg);
+    if (threadIdx.x == 0) partial[blockIdx.x] = sum;
+}
+
+// SetupGeneralAttributes (:37-46) + ComputeLuminanceWhite (:104-107) on the sorted luminances.
+// params: [0] average luminance, [1] luminance white.
+__global__ __launch_bounds__(IMG_BLOCK) void k_tm_params(const double *partial, int n_partial, const float *sorted, int64_t npx, float burn_percent, float *params) {
+    using Reduce = hipcub::BlockReduce<double, IMG_BLOCK>;
+    __shared__ typename Reduce::TempStorage tmp;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n_partial; i += IMG_BLOCK) acc += partial[i];
+    const double sum = Reduce(tmp).Sum(acc);
+    if (threadIdx.x != 0) return;
+    float s = (float)sum;
+    s = s / (float)npx;                                               // luminanceSum /= GetImageSize()
+    params[0] = (float)exp((double)s);
+    const float pos = (float)npx * (100.f - burn_percent) / 100.f;
+    double ri = round((double)pos);
+    if (!(ri >= 0.0)) ri = 0.0;                                       // outside [0, n) the reference indexes out of bounds
+    int64_t idx = (int64_t)ri;
+    if (idx > npx - 1) idx = npx - 1;
+    params[1] = sorted[idx] / sorted[npx - 1];
+}
+
+// ComputeTonemappedPixelColor (:79-102).
+template <bool FROM8>
+__global__ __launch_bounds__(IMG_BLOCK) void k_tm_apply(const void *src, int64_t npx, const float *params, float key, float saturation, float *out) {
+    const int64_t i = (int64_t)blockIdx.x * IMG_BLOCK + threadIdx.x;
+    if (i >= npx) return;
+    float r, g, b;
+    tm_load<FROM8>(src, i, r, g, b);
+    const float avg = params[0], lw = params[1];
+    const float l = tm_lum(r, g, b);
+    const float reg = l * key / avg;
+    const float res = (reg * (1 + (reg / (lw * lw)))) / (1 + reg);
+    float *o = out + 3 * i;
+    o[0] = powf(r / l, saturation) * res;
+    o[1] = powf(g / l, saturation) * res;
+    o[2] = powf(b / l, saturation) * res;
+}
+
+inline unsigned blocks_for(int64_t n) { return (unsigned)((n + IMG_BLOCK - 1) / IMG_BLOCK); }
+
+}  // namespace
+
+hipError_t rt_img_resolve8(hipStream_t s, const float *hdr, int64_t n_values, uint8_t *out) {
+    if (n_values <= 0) return hipSuccess;
+    int64_t done = 0;
+    if ((reinterpret_cast<uintptr_t>(hdr) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 3u) == 0 && n_values >= 4) {
+        const int64_t n4 = n_values / 4;
+        hipLaunchKernelGGL(k_resolve8_vec, dim3(blocks_for(n4)), dim3(IMG_BLOCK), 0, s, reinterpret_cast<const float4 *>(hdr), n4, reinterpret_cast<uint32_t *>(out));
+        done = 4 * n4;
+    }
+    if (done < n_values) hipLaunchKernelGGL(k_resolve8, dim3(blocks_for(n_values - done)), dim3(IMG_BLOCK), 0, s, hdr, done, n_values, out);
+    return hipGetLastError();
+}
+
+int64_t rt_img_p3_blocks(int64_t npx) { return (npx + IMG_BLOCK - 1) / IMG_BLOCK; }
+
+hipError_t rt_img_p3_scan_bytes(int64_t npx, size_t *bytes) {
+    *bytes = 0;
+    return hipcub::DeviceScan::ExclusiveSum(nullptr, *bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (int)(rt_img_p3_blocks(npx) + 1));
+}
+
+// block_len / block_off hold blocks+1 entries; block_off[blocks] is the length of the whole body.
+hipError_t rt_img_p3_measure(hipStream_t s, const uint8_t *rgb, int64_t npx, int nx, unsigned long long *block_len, unsigned long long *block_off,
+                             void *scan_tmp, size_t scan_bytes) {
+    const int64_t nb = rt_img_p3_blocks(npx);
+    hipError_t e = hipMemsetAsync(block_len + nb, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_p3_len, dim3((unsigned)nb), dim3(IMG_BLOCK), 0, s, rgb, (unsigned)npx, (unsigned)nx, block_len);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    return hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, block_len, block_off, (int)(nb + 1), s);
+}
+
+hipError_t rt_img_p3_write(hipStream_t s, const uint8_t *rgb, int64_t npx, int nx, const unsigned long long *block_off, uint8_t *out_body) {
+    hipLaunchKernelGGL(k_p3_write, dim3((unsigned)rt_img_p3_blocks(npx)), dim3(IMG_BLOCK), 0, s, rgb, (unsigned)npx, (unsigned)nx, block_off, out_body);
+    return hipGetLastError();
+}
+
+hipError_t rt_img_sort_bytes(int64_t npx, size_t *bytes) {
+    *bytes = 0;
+    return hipcub::DeviceRadixSort::SortKeys(nullptr, *bytes, (const float *)nullptr, (float *)nullptr, (int)npx);
+}
+
+hipError_t rt_img_tonemap(hipStream_t s, const void *src, int from8, int64_t npx, float key, float burn_percent, float saturation,
+                          float *lum, float *sorted, double *partial, float *params, void *sort_tmp, size_t sort_bytes, float *out) {
+    const unsigned nb = blocks_for(npx);
+    if (from8) hipLaunchKernelGGL(k_tm_lum<true>, dim3(nb), dim3(IMG_BLOCK), 0, s, src, npx, lum, partial);
+    else hipLaunchKernelGGL(k_tm_lum<false>, dim3(nb), dim3(IMG_BLOCK), 0, s, src, npx, lum, partial);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // HeapifyLuminanceVector (:73-77) is an ascending sort
+    if ((e = hipcub::DeviceRadixSort::SortKeys(sort_tmp, sort_bytes, (const float *)lum, sorted, (int)npx, 0, 32, s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_tm_params, dim3(1), dim3(IMG_BLOCK), 0, s, partial, (int)nb, sorted, npx, burn_percent, params);
+    if (from8) hipLaunchKernelGGL(k_tm_apply<true>, dim3(nb), dim3(IMG_BLOCK), 0, s, src, npx, params, key, saturation, out);
+    else hipLaunchKernelGGL(k_tm_apply<false>, dim3(nb), dim3(IMG_BLOCK), 0, s, src, npx, params, key, saturation, out);
+    return hipGetLastError();
+}

@@ -89,4 +89,15 @@ void rt_set_trace_block_cap(int cap);   // experiment hook: upper bound of the p
 int rt_trace_grid_threads();     // number of persistent threads the trace kernels are launched with
 int rt_trace_lds_stack_depth();  // stack entries kept in LDS per lane
 
+// rt_image.hip: frame post-processing (8-bit resolve, P3 text, tone mapping); all pointers are device pointers.
+hipError_t rt_img_resolve8(hipStream_t s, const float *hdr, int64_t n_values, uint8_t *out);
+int64_t rt_img_p3_blocks(int64_t npx);
+hipError_t rt_img_p3_scan_bytes(int64_t npx, size_t *bytes);
+hipError_t rt_img_p3_measure(hipStream_t s, const uint8_t *rgb, int64_t npx, int nx, unsigned long long *block_len, unsigned long long *block_off,
+                             void *scan_tmp, size_t scan_bytes);
+hipError_t rt_img_p3_write(hipStream_t s, const uint8_t *rgb, int64_t npx, int nx, const unsigned long long *block_off, uint8_t *out_body);
+hipError_t rt_img_sort_bytes(int64_t npx, size_t *bytes);
+hipError_t rt_img_tonemap(hipStream_t s, const void *src, int from8, int64_t npx, float key, float burn_percent, float saturation,
+                          float *lum, float *sorted, double *partial, float *params, void *sort_tmp, size_t sort_bytes, float *out);
+
 #endif

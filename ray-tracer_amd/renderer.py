@@ -55,6 +55,10 @@ def library():
     L.rt_host_bvh_free.argtypes = [C.c_void_p]
     L.rt_host_bvh_free.restype = None
     L.rt_abi_sizeof.argtypes = [C.c_int]
+    L.rt_image_encode_bound.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.rt_image_encode_bound.restype = C.c_size_t
+    L.rt_image_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, P(C.c_size_t), P(C.c_double)]
+    L.rt_tonemap.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, P(abi.TonemapOpts), C.c_void_p, C.c_void_p, P(C.c_double)]
     if L.rt_abi_version() != abi.RT_ABI_VERSION:
         raise RtError(abi.RT_ERR_ABI, "librt_mi355.so ABI %d != python mirror %d" % (L.rt_abi_version(), abi.RT_ABI_VERSION))
     _lib = L
@@ -187,6 +191,36 @@ class Context:
         return (hits, st) if stats else hits
 
 
+    def encode_image(self, hdr, fmt=abi.RT_IMG_PPM_P3, nx=None, ny=None, timing=False):
+        """8-bit resolve + image encoding on the device (ObtainColorFromUnclampedVector, Image::SaveImageAsPPM).  `hdr` is a
+        float32 numpy frame [ny, nx, 3] or a device pointer (int) with nx, ny given.  Returns the encoded bytes."""
+        on_device = isinstance(hdr, int)
+        if not on_device:
+            hdr = np.ascontiguousarray(hdr, np.float32)
+            ny, nx = hdr.shape[0], hdr.shape[1]
+        cap = self.L.rt_image_encode_bound(nx, ny, fmt)
+        out = np.empty(max(cap, 1), np.uint8)
+        n, ms = C.c_size_t(0), C.c_double(0)
+        self._check(self.L.rt_image_encode(self.h, hdr if on_device else hdr.ctypes.data, nx, ny, int(on_device), fmt, out.ctypes.data, cap,
+                                           C.byref(n), C.byref(ms) if timing else None))
+        return (out[:n.value], ms.value) if timing else out[:n.value]
+
+    def tonemap(self, hdr, key, burn_percent, saturation, gamma=2.2, input_8bit=True, nx=None, ny=None, timing=False):
+        """Tonemapper::Tonemap (DefaultTonemapStrategy) on the device.  Returns (rgb float32 [ny, nx, 3], (average luminance,
+        luminance white)[, ms])."""
+        on_device = isinstance(hdr, int)
+        if not on_device:
+            hdr = np.ascontiguousarray(hdr, np.float32)
+            ny, nx = hdr.shape[0], hdr.shape[1]
+        o = abi.TonemapOpts(abi.RT_ABI_VERSION, key, burn_percent, saturation, gamma, int(input_8bit), int(on_device), 0)
+        out = np.zeros((ny, nx, 3), np.float32)
+        params = np.zeros(2, np.float32)
+        ms = C.c_double(0)
+        self._check(self.L.rt_tonemap(self.h, hdr if on_device else hdr.ctypes.data, nx, ny, C.byref(o), out.ctypes.data, params.ctypes.data,
+                                      C.byref(ms) if timing else None))
+        return (out, params, ms.value) if timing else (out, params)
+
+
 class Mi355Accelerator:
     """AccelerationStructure mirror (src/AccelerationStructure.h:12-26): built from a scene's primitives, answers closest-
     hit queries — batched, because one ray per call cannot feed a GPU.  "No hit" is shape == -1 (reference: mat == nullptr)."""
@@ -218,14 +252,15 @@ class Mi355Renderer:
             hdr, pid, pt, st = self.ctx.render(i, seed=self.seed, timing=1)
             self.frames[cam["image_name"]] = hdr
             self.stats[cam["image_name"]] = st
-            write_ppm(os.path.join(self.out_dir, cam["image_name"]), resolve_8bit(hdr))
+            with open(os.path.join(self.out_dir, cam["image_name"]), "wb") as f:      # Image::SaveImage without <Tonemap>
+                f.write(self.ctx.encode_image(hdr, abi.RT_IMG_PPM_P3).tobytes())
 
     def close(self):
         self.ctx.close()
 
 
 def write_ppm(path, rgb8):
-    """Image::SaveImageAsPPM (src/Image.cpp:54-77): "P3\\n<w> <h>\\n255\\n", then per image row every channel as "%d "
+    """Host writer for an 8-bit numpy image (Context.encode_image is the device path).  Image::SaveImageAsPPM (src/Image.cpp:54-77): "P3\\n<w> <h>\\n255\\n", then per image row every channel as "%d "
     and a newline."""
     h, w, _ = rgb8.shape
     with open(path, "w") as f:

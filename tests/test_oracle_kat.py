@@ -187,3 +187,22 @@ def test_perlin_lattice_and_range(rt, orc):
     assert 0.0 <= min(vals) and max(vals) <= 1.0 and max(vals) - min(vals) > 0.3
     tx["noise_conversion"] = abi.RT_NOISE_ABSVAL
     assert all(f(*(np.random.RandomState(i).rand(3) * 20 - 10)) >= 0 for i in range(50))
+
+
+def test_image_writer_and_tonemap_restatements(orc):
+    """Hand-derived answers for the post-frame helpers: ObtainColorFromUnclampedVector, Image::SaveImageAsPPM's text and the
+    tone mapper's formulas (against float64 on a frame small enough for the float sum to be exact to ~1e-6)."""
+    f = np.array([[[0.0, 0.999, 1.0], [254.999, 255.0, 255.5]], [[1e9, 37.7, 128.49], [9.99, 10.0, 100.0]]], np.float32)
+    img = orc.resolve_8bit(f)
+    assert img.reshape(-1).tolist() == [0, 0, 1, 254, 255, 255, 255, 37, 128, 9, 10, 100]
+    assert orc.ppm_p3(img) == b"P3\n2 2\n255\n0 0 1 254 255 255 \n255 37 128 9 10 100 \n"
+    ch = img.astype(np.float32)
+    out, (avg, lw) = orc.tonemap(ch, 0.18, 25.0, 0.8)
+    lum = 0.27 * ch[..., 0].astype(np.float64) + 0.67 * ch[..., 1] + 0.06 * ch[..., 2]
+    assert abs(avg - np.exp(np.log(lum + 0.00001).mean())) < 1e-5 * avg
+    srt = np.sort(lum.reshape(-1))
+    assert abs(lw - srt[3] / srt[-1]) < 1e-6                            # round(4 * 75 / 100) = 3
+    reg = lum * 0.18 / avg
+    res = reg * (1 + reg / (lw * lw)) / (1 + reg)
+    want = (ch / lum[..., None]) ** 0.8 * res[..., None]
+    assert np.allclose(out, want, rtol=1e-5)
