@@ -248,8 +248,14 @@ int rt_scene_upload(rt_ctx *c, const rt_scene_desc *scene) {
         UPLOAD(c, c->d_prims, h.prims);
     }
     UPLOAD(c, c->d_objects, h.objects);
-    UPLOAD(c, c->d_verts, h.verts);
-    UPLOAD(c, c->d_tri_vert, h.tri_vert);
+    if (gs.verts) {       // shape setup ran on the device as well (rt_ingest.hip)
+        c->d_verts.release(); c->d_tri_vert.release();
+        c->d_verts.p = gs.verts; c->d_verts.cap = (size_t)std::max<int64_t>(1, gs.n_verts);
+        c->d_tri_vert.p = gs.tri_vert; c->d_tri_vert.cap = (size_t)std::max<int64_t>(1, 3 * gs.n_tris);
+    } else {
+        UPLOAD(c, c->d_verts, h.verts);
+        UPLOAD(c, c->d_tri_vert, h.tri_vert);
+    }
     UPLOAD(c, c->d_materials, h.materials);
     UPLOAD(c, c->d_lights, h.lights);
     UPLOAD(c, c->d_textures, h.textures);

@@ -50,9 +50,27 @@ struct RtGpuScene {
     int32_t root = 0;
     float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
     int max_depth = 0, stack_bound = 0;
+    DevVertex *verts = nullptr;        // set when the scene was ingested on the device (rt_ingest.hip), else null
+    int32_t *tri_vert = nullptr;
+    int64_t n_verts = 0, n_tris = 0;
 };
-// Build and flatten on the GPU: shape_rec = one DevPrim per shape, pshape[i] = shape of reference primitive i (host arrays).
-bool rt_bvh_gpu_build_flatten(const float *pbox, int64_t n, const DevPrim *shape_rec, int64_t n_shapes, const int32_t *pshape, RtGpuScene &out, std::string &err);
+// Build and flatten on the GPU: shape_rec = one DevPrim per shape, pshape[i] = shape of reference primitive i; host arrays, or
+// device arrays (left untouched, still owned by the caller) when inputs_on_device is set.
+bool rt_bvh_gpu_build_flatten(const float *pbox, int64_t n, const DevPrim *shape_rec, int64_t n_shapes, const int32_t *pshape, RtGpuScene &out, std::string &err,
+                              bool inputs_on_device = false);
+
+// Shape setup on the device (rt_ingest.hip): triangle records, smooth vertex normals, primitive world boxes — all device memory.
+struct RtGpuIngest {
+    float *pbox = nullptr;             // [6 * n_prims]
+    DevPrim *shape_rec = nullptr;      // [n_triangles + n_spheres]
+    int32_t *pshape = nullptr;         // [n_prims]
+    DevVertex *verts = nullptr;        // [n_vertices]
+    int32_t *tri_vert = nullptr;       // [3 * n_triangles]
+    void release();
+};
+// RT_OK, a negative rt_status, or 1 = "use the host loops" (a vertex shared by two smooth objects).  The description must have
+// been range-checked; sphere_rec holds the sphere records (host).
+int rt_ingest_gpu(const rt_scene_desc *d, const std::vector<DevObject> &objects, const std::vector<DevPrim> &sphere_rec, RtGpuIngest &out, std::string &err);
 
 // Returns 0 or a negative rt_status; `err` receives a message.  gpu_build: build the tree with rt_bvh_gpu_build when the scene
 // has at least RT_GPU_BUILD_MIN_PRIMS primitives (the flattening stays on the host); the result is the same either way.

@@ -97,9 +97,57 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
         q.material = o.material; q.tex_color = o.tex_color; q.tex_normal = o.tex_normal; q._pad = 0;
     }
 
+    // ---- large scenes: shape setup, build and flattening all on the device (rt_ingest.hip, rt_bvh_gpu.hip) -----------
+    const bool want_gpu = d->n_prims > 0 && (gpu_build == 2 || (gpu_build == 1 && d->n_prims >= RT_GPU_BUILD_MIN_PRIMS && !getenv("RT_HOST_BUILD")));
+    bool device_done = false;
+    int maxDepth = 0;
+    if (want_gpu && device_out && !getenv("RT_HOST_FLATTEN") && !getenv("RT_HOST_INGEST")) {
+        const int64_t nT = d->n_triangles, nS = d->n_spheres, nP = d->n_prims;
+        for (int64_t t = 0; t < nT; ++t) {                                // the range checks of the host loops below
+            const int32_t *iv = d->tri_vert + 3 * t;
+            const int32_t ob = d->tri_object[t];
+            if (ob < 0 || ob >= d->n_objects) { err = "triangle references a missing object"; return RT_ERR_INVALID; }
+            for (int k = 0; k < 3; ++k) if (iv[k] < 0 || iv[k] >= d->n_vertices) { err = "triangle references a missing vertex"; return RT_ERR_INVALID; }
+        }
+        std::vector<DevPrim> sphereRec((size_t)nS);
+        for (int64_t s = 0; s < nS; ++s) {                                   // Sphere.cpp:9-21
+            const int32_t ob = d->sph_object[s];
+            if (ob < 0 || ob >= d->n_objects) { err = "sphere references a missing object"; return RT_ERR_INVALID; }
+            DevPrim &r = sphereRec[(size_t)s];
+            std::memset(&r, 0, sizeof(r));
+            r.p0[0] = d->sph_center_radius[4 * s]; r.p0[1] = d->sph_center_radius[4 * s + 1]; r.p0[2] = d->sph_center_radius[4 * s + 2];
+            r.e1[0] = d->sph_center_radius[4 * s + 3];
+            r.object = ob; r.shape = (int32_t)s | RT_PRIM_SPHERE; r.kind = DEV_PRIM_SPHERE;
+        }
+        for (int64_t i = 0; i < nP; ++i) {
+            const int32_t ref = d->prim_shape[i];
+            if ((ref & RT_PRIM_INDEX_MASK) >= ((ref & RT_PRIM_SPHERE) ? nS : nT)) { err = "primitive references a missing shape"; return RT_ERR_INVALID; }
+        }
+        lap("tables, range checks");
+        RtGpuIngest ing;
+        const int irc = rt_ingest_gpu(d, hs.objects, sphereRec, ing, err);
+        if (irc < 0) return irc;
+        if (irc == RT_OK) {
+            const bool ok = rt_bvh_gpu_build_flatten(ing.pbox, nP, ing.shape_rec, nT + nS, ing.pshape, *device_out, err, /*inputs_on_device=*/true);
+            if (!ok) { ing.release(); return RT_ERR_HIP; }
+            device_out->verts = ing.verts; device_out->tri_vert = ing.tri_vert; device_out->n_verts = d->n_vertices; device_out->n_tris = nT;
+            ing.verts = nullptr; ing.tri_vert = nullptr;
+            ing.release();
+            maxDepth = device_out->max_depth;
+            device_done = true;
+            hs.verts.clear(); hs.tri_vert.clear();
+            lap("device ingest + build");
+        }
+    }
+
+    std::vector<DevPrim> shapeRec;
+    std::vector<int32_t> pshape, order;
+    std::vector<BuildNode> bn;
+    const int64_t nP = d->n_prims;
+    if (!device_done) {
     // ---- triangles: edges, face normal, object box; smooth vertex normals --------------------------
     const int64_t nT = d->n_triangles, nS = d->n_spheres;
-    std::vector<DevPrim> shapeRec(nT + nS);
+    shapeRec.assign((size_t)(nT + nS), DevPrim());
     std::vector<Aabb> shapeBox(nT + nS);
     hs.verts.assign(d->n_vertices, DevVertex());
     for (int64_t v = 0; v < d->n_vertices; ++v) {
@@ -163,9 +211,8 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
 
     lap("tables, triangles, normals");
     // ---- reference primitives and their world boxes (Q5, Q29) -------------------------------------
-    const int64_t nP = d->n_prims;
     std::vector<Aabb> pbox(nP);
-    std::vector<int32_t> pshape(nP);           // index into shapeRec
+    pshape.assign((size_t)nP, 0);              // index into shapeRec
     for (int64_t i = 0; i < nP; ++i) {
         int32_t ref = d->prim_shape[i];
         int64_t idx = ref & RT_PRIM_INDEX_MASK;
@@ -185,12 +232,9 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
 
     lap("primitive boxes");
     // ---- BVH build (BVHTree.cpp:39-153), explicit work stack, nodes created in preorder ------------
-    std::vector<int32_t> order(nP);
+    order.assign((size_t)nP, 0);
     for (int64_t i = 0; i < nP; ++i) order[i] = (int32_t)i;
-    std::vector<BuildNode> bn;
-    int maxDepth = 0;
-    bool built = false, device_done = false;
-    const bool want_gpu = nP > 0 && (gpu_build == 2 || (gpu_build == 1 && nP >= RT_GPU_BUILD_MIN_PRIMS && !getenv("RT_HOST_BUILD")));
+    bool built = false;
     if (want_gpu && device_out && !getenv("RT_HOST_FLATTEN")) {
         // build AND flatten on the device: the traversal arrays never exist on the host
         static_assert(sizeof(Aabb) == 6 * sizeof(float), "Aabb must be six packed floats (lo, hi)");
@@ -255,11 +299,16 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
             if (bn[i].left >= 0) bn[i].box = merge(bn[bn[i].left].box, bn[bn[i].right].box);
     }
 
+    }
+
     lap("reference BVH build");
     // ---- flatten ------------------------------------------------------------------------------------
     hs.nodes.clear(); hs.chain.clear(); hs.leaves.clear(); hs.prims.clear(); hs.ref_leaf_range.clear(); hs.leaf_boxes.clear();
-    hs.ref_prim_order.resize(nP);
-    for (int64_t i = 0; i < nP; ++i) hs.ref_prim_order[i] = shapeRec[pshape[order[i]]].shape;
+    hs.ref_prim_order.clear();
+    if (!device_done) {
+        hs.ref_prim_order.resize(nP);
+        for (int64_t i = 0; i < nP; ++i) hs.ref_prim_order[i] = shapeRec[pshape[order[i]]].shape;
+    }
     std::memset(&hs.params, 0, sizeof(hs.params));
     hs.params.root = RT_NO_ROOT;
     auto store3 = [](float *dst, f3 v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; };

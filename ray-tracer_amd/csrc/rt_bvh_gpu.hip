@@ -441,12 +441,13 @@ struct GpuBuild {
     Tree t = {nullptr, nullptr, nullptr, nullptr, nullptr};
     Level lv = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t st = nullptr;
-    bool tm = false;
+    bool tm = false, own_box = true;
     double t_mark = 0;
     void lap(const char *what) { if (tm) { const double tn = now_ms(); fprintf(stderr, "[rt gpu build] %-24s %8.2f ms\n", what, tn - t_mark); t_mark = tn; } }
 
-    bool build(const float *pbox, int n_, std::string &err) {
+    bool build(const float *pbox, int n_, std::string &err, bool box_on_device = false) {
         n = n_;
+        own_box = !box_on_device;
         bool ok = true;
         tm = getenv("RT_BUILD_TIMING") != nullptr;
         t_mark = now_ms();
@@ -454,7 +455,8 @@ struct GpuBuild {
         int base = 0, cnt = 1;
         const dim3 blk(256), grid_n((n + 1 + 255) / 256), grid_r((n + 256 * GB_ITEMS - 1) / (256 * GB_ITEMS));
         {
-            GB_TRY(dalloc(&d_box, 6 * (size_t)n)); GB_TRY(dalloc(&d_order, (size_t)n)); GB_TRY(dalloc(&d_node_of, (size_t)n));
+            if (own_box) GB_TRY(dalloc(&d_box, 6 * (size_t)n)); else d_box = const_cast<float *>(pbox);
+            GB_TRY(dalloc(&d_order, (size_t)n)); GB_TRY(dalloc(&d_node_of, (size_t)n));
             GB_TRY(dalloc(&d_flag, (size_t)n + 1)); GB_TRY(dalloc(&d_scan, (size_t)n + 1)); GB_TRY(dalloc(&d_pairL, (size_t)n)); GB_TRY(dalloc(&d_pairR, (size_t)n));
             GB_TRY(dalloc(&d_bin, (size_t)n)); GB_TRY(dalloc(&d_next, 4));
             GB_TRY(dalloc(&t.start, cap)); GB_TRY(dalloc(&t.end, cap)); GB_TRY(dalloc(&t.left, cap)); GB_TRY(dalloc(&t.depth, cap)); GB_TRY(dalloc(&t.box, 6 * cap));
@@ -464,7 +466,7 @@ struct GpuBuild {
             GB_TRY(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
             GB_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
             lap("allocate");
-            GB_TRY(hipMemcpyAsync(d_box, pbox, 6 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
+            if (own_box) GB_TRY(hipMemcpyAsync(d_box, pbox, 6 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(k_fill, grid_n, blk, 0, st, d_order, n, 0, 1);
             hipLaunchKernelGGL(k_fill, grid_n, blk, 0, st, d_node_of, n, 0, 0);
             {   // root
@@ -505,7 +507,8 @@ struct GpuBuild {
         return ok;
     }
     void release() {
-        hipFree(d_box); hipFree(d_order); hipFree(d_node_of); hipFree(d_flag); hipFree(d_scan); hipFree(d_pairL); hipFree(d_pairR); hipFree(d_bin);
+        if (own_box) hipFree(d_box);
+        hipFree(d_order); hipFree(d_node_of); hipFree(d_flag); hipFree(d_scan); hipFree(d_pairL); hipFree(d_pairR); hipFree(d_bin);
         hipFree(d_next); hipFree(d_tmp); hipFree(t.start); hipFree(t.end); hipFree(t.left); hipFree(t.depth); hipFree(t.box);
         hipFree(lv.all); hipFree(lv.binCount); hipFree(lv.binBox); hipFree(lv.ax); hipFree(lv.split); hipFree(lv.mid); hipFree(lv.clo); hipFree(lv.chi);
         if (st) hipStreamDestroy(st);
@@ -553,11 +556,12 @@ done:
 
 // Build AND flatten on the device: the scene arrays the traversal reads never exist on the host.  shape_rec: one 64-byte
 // DevPrim per shape (host), pshape: shape of every reference primitive (host).  On success the caller owns out.* (hipFree).
-bool rt_bvh_gpu_build_flatten(const float *pbox, int64_t n64, const DevPrim *shape_rec, int64_t n_shapes, const int32_t *pshape, RtGpuScene &out, std::string &err) {
+bool rt_bvh_gpu_build_flatten(const float *pbox, int64_t n64, const DevPrim *shape_rec, int64_t n_shapes, const int32_t *pshape, RtGpuScene &out, std::string &err,
+                              bool inputs_on_device) {
     out = RtGpuScene();
     if (n64 <= 0) { err = "empty scene"; return false; }
     GpuBuild g;
-    bool ok = g.build(pbox, (int)n64, err);
+    bool ok = g.build(pbox, (int)n64, err, inputs_on_device);
     float4 *d_shape = nullptr; int *d_pshape = nullptr, *d_uniq = nullptr, *d_dev_start = nullptr, *d_leaf_ref = nullptr, *d_cnt = nullptr;
     int2 *d_work[2] = {nullptr, nullptr};
     if (ok) {
@@ -566,9 +570,13 @@ bool rt_bvh_gpu_build_flatten(const float *pbox, int64_t n64, const DevPrim *sha
         const dim3 blk(256), grid_n((n + 1 + 255) / 256), grid_nodes((n_nodes + 255) / 256);
         int n_leaves = 0, n_leaf_prims = 0;
         {
-            GB_TRY(dalloc(&d_shape, 4 * (size_t)n_shapes)); GB_TRY(dalloc(&d_pshape, (size_t)n));
-            GB_TRY(hipMemcpyAsync(d_shape, shape_rec, (size_t)n_shapes * sizeof(DevPrim), hipMemcpyHostToDevice, st));
-            GB_TRY(hipMemcpyAsync(d_pshape, pshape, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+            if (inputs_on_device) {
+                d_shape = reinterpret_cast<float4 *>(const_cast<DevPrim *>(shape_rec)); d_pshape = const_cast<int *>(pshape);
+            } else {
+                GB_TRY(dalloc(&d_shape, 4 * (size_t)n_shapes)); GB_TRY(dalloc(&d_pshape, (size_t)n));
+                GB_TRY(hipMemcpyAsync(d_shape, shape_rec, (size_t)n_shapes * sizeof(DevPrim), hipMemcpyHostToDevice, st));
+                GB_TRY(hipMemcpyAsync(d_pshape, pshape, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+            }
             // leaves in order of their range start
             GB_TRY(hipMemsetAsync(g.d_flag, 0, ((size_t)n + 1) * sizeof(int), st));
             hipLaunchKernelGGL(k_mark_leaves, grid_nodes, blk, 0, st, g.t, n_nodes, g.d_flag);
@@ -631,7 +639,8 @@ bool rt_bvh_gpu_build_flatten(const float *pbox, int64_t n64, const DevPrim *sha
         }
     }
 done:
-    hipFree(d_shape); hipFree(d_pshape); hipFree(d_uniq); hipFree(d_dev_start); hipFree(d_leaf_ref); hipFree(d_cnt); hipFree(d_work[0]); hipFree(d_work[1]);
+    if (!inputs_on_device) { hipFree(d_shape); hipFree(d_pshape); }
+    hipFree(d_uniq); hipFree(d_dev_start); hipFree(d_leaf_ref); hipFree(d_cnt); hipFree(d_work[0]); hipFree(d_work[1]);
     if (!ok) { hipFree(out.nodes); hipFree(out.chain); hipFree(out.leaves); hipFree(out.prims); out = RtGpuScene(); }
     g.release();
     return ok;

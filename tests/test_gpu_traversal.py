@@ -155,3 +155,72 @@ def test_gpu_bvh_build_large(rt):
         assert np.array_equal(h["leaf_start_end"], g["leaf_start_end"])
         assert np.array_equal(h["prim_order"], g["prim_order"])
         assert np.array_equal(h["leaf_boxes"], g["leaf_boxes"])
+
+
+def _ingest_scene(rt, shared_vertices=False):
+    """Smooth and flat meshes, a sphere, a moving instance: every branch of the shape set-up."""
+    b = rt.SceneBuilder()
+    s = b.soup
+    s.max_depth = 2
+    s.ambient = np.array([20, 20, 20], np.float32)
+    b.add_lookat_camera((0, -30, 12), (0, 0, 0), (0, 0, 1), 40.0, 1.0, 160, 120)
+    b.add_light(abi.RT_LIGHT_POINT, (10, -20, 30), (9e4, 9e4, 9e4))
+    m = b.add_material(abi.RT_MAT_DEFAULT, (1, 1, 1), (0.6, 0.5, 0.4), (0.3, 0.3, 0.3), phong=10)
+    mm = b.add_material(abi.RT_MAT_MIRROR, (0, 0, 0), (0.3, 0.3, 0.3), (0, 0, 0), (0.6, 0.6, 0.6), phong=1)
+    pos, faces = synth.torus_knot_mesh(6000, 3, extent=14.0, center=(0.0, 0.0, 4.0))
+    big = b.add_mesh(pos, faces, material=m, smooth=True)
+    pos2, faces2 = synth.torus_knot_mesh(1500, 5, extent=5.0, center=(9.0, 3.0, 2.0))
+    b.add_mesh(pos2, faces2, material=mm, smooth=True, xform=synth.mat_rotate(30.0, (0, 0, 1)))
+    floor = np.array([[-40, -40, -6], [40, -40, -6], [40, 40, -6], [-40, 40, -6]], np.float32)
+    b.add_mesh(floor, [[0, 1, 2], [2, 3, 0]], material=mm)
+    b.add_sphere((-8, -4, 0), 3.0, xform=synth.mat_identity(), material=m)
+    b.add_instance(big, synth.mat_translate((0.0, 12.0, 0.0)), motion_blur=(0, 0, 3))
+    soup = b.finish("ingest")
+    if shared_vertices:                                                 # a smooth triangle of mesh 2 that uses a vertex of mesh 1
+        soup.tri_vert = soup.tri_vert.copy()
+        first2 = int(np.nonzero(soup.tri_object == 1)[0][0])
+        soup.tri_vert[first2, 0] = 0
+    return soup
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_device_ingest_equals_host_loops(rt, orc, shared):
+    """Shape set-up on the device (triangle records, smooth vertex normals in the reference's summation order, primitive
+    boxes incl. motion blur) against the host loops: same frame bit for bit, and hit normals equal to the oracle's.  With a
+    vertex shared between two smooth meshes the device path must hand over to the host loops."""
+    soup = _ingest_scene(rt, shared)
+    assert len(soup.prim_shape) >= 4096
+    old = os.environ.get("RT_HOST_INGEST")
+    frames, hits = [], []
+    rng = np.random.RandomState(9)
+    rays = np.zeros(20000, abi.ray_dtype)
+    o = np.array([0.0, -30.0, 12.0]) + (rng.rand(20000, 3) - 0.5)
+    d = (rng.rand(20000, 3) - 0.5) * np.array([30.0, 20.0, 16.0]) - o
+    rays["origin"], rays["direction"] = o.astype(np.float32), (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays["time"] = rng.rand(20000).astype(np.float32)
+    try:
+        for host in ("0", "1"):
+            if host == "1":
+                os.environ["RT_HOST_INGEST"] = "1"
+            else:
+                os.environ.pop("RT_HOST_INGEST", None)
+            ctx = rt.Context(0)
+            ctx.upload(soup)
+            frames.append(ctx.render(0)[0])
+            hits.append(ctx.intersect(rays))
+            ctx.close()
+    finally:
+        if old is None:
+            os.environ.pop("RT_HOST_INGEST", None)
+        else:
+            os.environ["RT_HOST_INGEST"] = old
+    assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
+    assert hits[0].tobytes() == hits[1].tobytes()
+    c = orc.OracleScene(soup).intersect(rays)
+    hit = c["shape"] >= 0
+    assert hit.sum() > 5000
+    assert np.array_equal(hits[0]["shape"], c["shape"])
+    assert np.array_equal(hits[0]["n"][hit].view(np.uint32), c["n"][hit].view(np.uint32))
+    tri = hit & ((c["shape"] & abi.RT_PRIM_SPHERE) == 0)                 # sphere uv goes through acosf / atan2f (last-ulp libm differences)
+    np.testing.assert_array_equal(hits[0]["uv"][tri], c["uv"][tri])
+    np.testing.assert_allclose(hits[0]["uv"][hit], c["uv"][hit], rtol=1e-4, atol=1e-6)
