@@ -276,7 +276,10 @@ int rt_resolve_8bit(const float *hdr_rgb, int64_t n_pixels, uint8_t *out_rgb);
 
 enum { RT_IMG_RGB8 = 0,      /* the reference's Image contents: ny*nx*3 unsigned chars                            */
        RT_IMG_PPM_P3 = 1,    /* the file Image::SaveImageAsPPM writes, byte for byte                                */
-       RT_IMG_PPM_P6 = 2 };  /* binary PPM of the same 8-bit image (not in the reference; 4-5x smaller)             */
+       RT_IMG_PPM_P6 = 2,    /* binary PPM of the same 8-bit image (not in the reference; 4-5x smaller)             */
+       RT_IMG_EXR_HALF = 3 };/* the file Tonemapper::SaveEXR writes through tinyexr (src/Tonemapper.cpp:34-99,
+                                src/tinyexr.h:12126-12598): channels B, G, R as HALF, uncompressed scan lines; the input
+                                frame is the float array rt_tonemap returns, no 8-bit step                             */
 
 /* Upper bound of the bytes rt_image_encode produces for an nx*ny frame in `format` (0 for bad arguments). */
 size_t rt_image_encode_bound(int nx, int ny, int format);

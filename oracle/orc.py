@@ -45,6 +45,8 @@ def lib():
         L.orc_tonemap.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.orc_ppm_p3.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         L.orc_ppm_p3.restype = C.c_size_t
+        L.orc_exr_half.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.orc_exr_half.restype = C.c_size_t
         L.orc_abi_version.restype = C.c_uint32
         assert L.orc_abi_version() == abi.RT_ABI_VERSION
         _LIB = L
@@ -145,3 +147,12 @@ def tonemap(channels, key, burn_percent, saturation):
     if rc != 0:
         raise RuntimeError("orc_tonemap rc=%d" % rc)
     return out, params
+
+
+def exr_half(rgb):
+    """Tonemapper::SaveEXR through tinyexr (uncompressed HALF scan lines, channels B, G, R) as bytes."""
+    v = np.ascontiguousarray(rgb, np.float32)
+    n = lib().orc_exr_half(v.ctypes.data, v.shape[1], v.shape[0], None, 0)
+    out = np.zeros(n, np.uint8)
+    lib().orc_exr_half(v.ctypes.data, v.shape[1], v.shape[0], out.ctypes.data, n)
+    return out.tobytes()

@@ -1486,6 +1486,100 @@ size_t orc_ppm_p3(const uint8_t *rgb, int nx, int ny, char *out, size_t cap) {
     return total;
 }
 
+// Tonemapper::SaveEXR (Tonemapper.cpp:34-99) through tinyexr's SaveEXRImageToMemory (tinyexr.h:12077-12598) into memory:
+// rgb is split into R, G, B planes, handed over as channels "B", "G", "R" (FLOAT in, HALF requested), compression NONE
+// (InitEXRHeader zeroes the header), one scan-line block per row.  Returns the file size (writes at most cap bytes).
+// PARITY UNPINNED: the reference ships no .exr output; this follows the vendored tinyexr source text.
+namespace orc {
+static uint16_t FloatToHalfFull(float v) {                             // tinyexr.h:7239-7274
+    uint32_t f; std::memcpy(&f, &v, 4);
+    const uint32_t Sign = f >> 31, Exponent = (f >> 23) & 0xff, Mantissa = f & 0x7fffff;
+    uint16_t o = 0;
+    if (Exponent == 0) o = 0;
+    else if (Exponent == 255) o = (uint16_t)((31u << 10) | (Mantissa ? 0x200 : 0));
+    else {
+        int newexp = (int)Exponent - 127 + 15;
+        if (newexp >= 31) o = (uint16_t)(31u << 10);
+        else if (newexp <= 0) {
+            if ((14 - newexp) <= 24) {
+                unsigned int mant = Mantissa | 0x800000;
+                o = (uint16_t)((mant >> (14 - newexp)) & 0x3ff);
+                if ((mant >> (13 - newexp)) & 1) o++;
+            }
+        } else {
+            o = (uint16_t)(((unsigned)newexp << 10) | (Mantissa >> 13));
+            if (Mantissa & 0x1000) o++;
+        }
+    }
+    return (uint16_t)((o & 0x7fff) | (Sign << 15));
+}
+static void WriteAttribute(std::vector<unsigned char> &out, const char *name, const char *type, const unsigned char *data, int len) {   // tinyexr.h:7379-7390
+    out.insert(out.end(), name, name + strlen(name) + 1);
+    out.insert(out.end(), type, type + strlen(type) + 1);
+    out.insert(out.end(), reinterpret_cast<unsigned char *>(&len), reinterpret_cast<unsigned char *>(&len) + sizeof(int));
+    out.insert(out.end(), data, data + len);
+}
+} // namespace orc
+
+size_t orc_exr_half(const float *rgb, int width, int height, unsigned char *out, size_t cap) {
+    std::vector<float> images[3];
+    for (int c = 0; c < 3; ++c) images[c].resize((size_t)width * height);
+    for (int i = 0; i < width * height; i++) { images[0][i] = rgb[3 * i + 0]; images[1][i] = rgb[3 * i + 1]; images[2][i] = rgb[3 * i + 2]; }
+    const float *image_ptr[3] = {images[2].data(), images[1].data(), images[0].data()};     // B, G, R
+    const char *names[3] = {"B", "G", "R"};
+    std::vector<unsigned char> memory;
+    const char header[] = {0x76, 0x2f, 0x31, 0x01};
+    memory.insert(memory.end(), header, header + 4);
+    const char marker[] = {2, 0, 0, 0};
+    memory.insert(memory.end(), marker, marker + 4);
+    {   // WriteChannelInfo, tinyexr.h:7502-7542
+        std::vector<unsigned char> data(3 * (2 + 16) + 1, 0);
+        unsigned char *p = data.data();
+        for (int c = 0; c < 3; c++) {
+            *p++ = (unsigned char)names[c][0]; *p++ = 0;
+            int pixel_type = 1 /* TINYEXR_PIXELTYPE_HALF */, x_sampling = 1, y_sampling = 1;
+            std::memcpy(p, &pixel_type, 4); p += 4;
+            *p = 0; p += 4;                                            // p_linear + 3 reserved
+            std::memcpy(p, &x_sampling, 4); p += 4;
+            std::memcpy(p, &y_sampling, 4); p += 4;
+        }
+        *p = 0;
+        orc::WriteAttribute(memory, "channels", "chlist", data.data(), (int)data.size());
+    }
+    { int comp = 0; orc::WriteAttribute(memory, "compression", "compression", reinterpret_cast<unsigned char *>(&comp), 1); }
+    {
+        int data[4] = {0, 0, width - 1, height - 1};
+        orc::WriteAttribute(memory, "dataWindow", "box2i", reinterpret_cast<unsigned char *>(data), 16);
+        orc::WriteAttribute(memory, "displayWindow", "box2i", reinterpret_cast<unsigned char *>(data), 16);
+    }
+    { unsigned char line_order = 0; orc::WriteAttribute(memory, "lineOrder", "lineOrder", &line_order, 1); }
+    { float aspectRatio = 1.0f; orc::WriteAttribute(memory, "pixelAspectRatio", "float", reinterpret_cast<unsigned char *>(&aspectRatio), 4); }
+    { float center[2] = {0.0f, 0.0f}; orc::WriteAttribute(memory, "screenWindowCenter", "v2f", reinterpret_cast<unsigned char *>(center), 8); }
+    { float w = (float)width; orc::WriteAttribute(memory, "screenWindowWidth", "float", reinterpret_cast<unsigned char *>(&w), 4); }
+    memory.push_back(0);
+    const int num_blocks = height;                                     // num_scanlines == 1 without compression
+    std::vector<uint64_t> offsets((size_t)num_blocks);
+    uint64_t offset = memory.size() + (uint64_t)num_blocks * sizeof(int64_t);
+    const int pixel_data_size = 3 * (int)sizeof(unsigned short);
+    std::vector<std::vector<unsigned char> > data_list((size_t)num_blocks);
+    for (int i = 0; i < num_blocks; i++) {
+        std::vector<unsigned char> buf((size_t)width * pixel_data_size);
+        for (int c = 0; c < 3; c++) {
+            unsigned char *line = buf.data() + (size_t)c * sizeof(unsigned short) * width;
+            for (int x = 0; x < width; x++) { uint16_t h = orc::FloatToHalfFull(image_ptr[c][(size_t)i * width + x]); std::memcpy(line + 2 * x, &h, 2); }
+        }
+        unsigned int data_len = (unsigned int)buf.size();
+        data_list[i].resize(8);
+        std::memcpy(&data_list[i][0], &i, 4); std::memcpy(&data_list[i][4], &data_len, 4);
+        data_list[i].insert(data_list[i].end(), buf.begin(), buf.end());
+    }
+    for (int i = 0; i < num_blocks; i++) { offsets[i] = offset; offset += data_list[i].size(); }
+    memory.insert(memory.end(), reinterpret_cast<unsigned char *>(offsets.data()), reinterpret_cast<unsigned char *>(offsets.data()) + 8 * (size_t)num_blocks);
+    for (int i = 0; i < num_blocks; i++) memory.insert(memory.end(), data_list[i].begin(), data_list[i].end());
+    if (out) std::memcpy(out, memory.data(), std::min(cap, memory.size()));
+    return memory.size();
+}
+
 // KAT hooks
 void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { orc::Philox4x32(ctr, key, out); }
 float orc_perlin(const rt_texture *tx, float x, float y, float z) { return orc::PerlinValue(*tx, x, y, z); }

@@ -96,7 +96,7 @@ class Stats(C.Structure):
                 "trace_rays": int(self.trace_rays), "ms_trace_busy": self.ms_trace_busy}
 
 
-RT_IMG_RGB8, RT_IMG_PPM_P3, RT_IMG_PPM_P6 = 0, 1, 2
+RT_IMG_RGB8, RT_IMG_PPM_P3, RT_IMG_PPM_P6, RT_IMG_EXR_HALF = 0, 1, 2, 3
 
 
 class TonemapOpts(C.Structure):

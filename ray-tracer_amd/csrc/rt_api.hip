@@ -681,6 +681,45 @@ static int ppm_header(char *buf, size_t cap, int format, int nx, int ny) {
     return std::snprintf(buf, cap, "P%d\n%d %d\n255\n", format == RT_IMG_PPM_P3 ? 3 : 6, nx, ny);   // Image.cpp:59-61
 }
 
+// Everything of an EXR file before the scan-line blocks, as SaveEXRImageToMemory (reference src/tinyexr.h:12126-12266,
+// 12569-12581) writes it for Tonemapper::SaveEXR's header (src/Tonemapper.cpp:34-99): magic, version, the attributes
+// channels (B, G, R as HALF) / compression (NONE: InitEXRHeader zeroes it) / dataWindow / displayWindow / lineOrder /
+// pixelAspectRatio / screenWindowCenter / screenWindowWidth, the terminator and the offset table (one block per row).
+static std::vector<unsigned char> exr_prefix(int nx, int ny) {
+    std::vector<unsigned char> m;
+    auto bytes = [&](const void *p, size_t n) { const unsigned char *b = static_cast<const unsigned char *>(p); m.insert(m.end(), b, b + n); };
+    auto attr = [&](const char *name, const char *type, const void *data, int len) {
+        bytes(name, std::strlen(name) + 1); bytes(type, std::strlen(type) + 1); bytes(&len, 4); bytes(data, (size_t)len);
+    };
+    const unsigned char magic[8] = {0x76, 0x2f, 0x31, 0x01, 2, 0, 0, 0};
+    bytes(magic, 8);
+    std::vector<unsigned char> ch;
+    for (const char *name : {"B", "G", "R"}) {
+        const int half = 1, one = 1;                       // TINYEXR_PIXELTYPE_HALF, sampling 1
+        const unsigned char plinear[4] = {0, 0, 0, 0};
+        ch.insert(ch.end(), name, name + 2);
+        const unsigned char *q = reinterpret_cast<const unsigned char *>(&half); ch.insert(ch.end(), q, q + 4);
+        ch.insert(ch.end(), plinear, plinear + 4);
+        q = reinterpret_cast<const unsigned char *>(&one); ch.insert(ch.end(), q, q + 4); ch.insert(ch.end(), q, q + 4);
+    }
+    ch.push_back(0);
+    attr("channels", "chlist", ch.data(), (int)ch.size());
+    const unsigned char comp = 0, line_order = 0;
+    attr("compression", "compression", &comp, 1);
+    const int window[4] = {0, 0, nx - 1, ny - 1};
+    attr("dataWindow", "box2i", window, 16);
+    attr("displayWindow", "box2i", window, 16);
+    attr("lineOrder", "lineOrder", &line_order, 1);
+    const float aspect = 1.0f, center[2] = {0.0f, 0.0f}, width = (float)nx;
+    attr("pixelAspectRatio", "float", &aspect, 4);
+    attr("screenWindowCenter", "v2f", center, 8);
+    attr("screenWindowWidth", "float", &width, 4);
+    m.push_back(0);
+    const uint64_t first = (uint64_t)m.size() + 8ull * (uint64_t)ny, row = 8ull + 6ull * (uint64_t)nx;
+    for (int y = 0; y < ny; ++y) { const uint64_t off = first + row * (uint64_t)y; bytes(&off, 8); }
+    return m;
+}
+
 size_t rt_image_encode_bound(int nx, int ny, int format) {
     if (nx <= 0 || ny <= 0) return 0;
     const size_t npx = (size_t)nx * (size_t)ny;
@@ -688,6 +727,7 @@ size_t rt_image_encode_bound(int nx, int ny, int format) {
     case RT_IMG_RGB8: return 3 * npx;
     case RT_IMG_PPM_P6: return 3 * npx + 40;
     case RT_IMG_PPM_P3: return 12 * npx + (size_t)ny + 40;
+    case RT_IMG_EXR_HALF: return exr_prefix(nx, ny).size() + (size_t)ny * (8 + 6 * (size_t)nx);
     default: return 0;
     }
 }
@@ -714,7 +754,7 @@ int rt_image_encode(rt_ctx *c, const float *hdr_rgb, int nx, int ny, int hdr_on_
                     size_t *out_bytes, double *ms_kernels) {
     if (!c) return RT_ERR_INVALID;
     if (out_bytes) *out_bytes = 0;
-    if (!hdr_rgb || !out_host || nx <= 0 || ny <= 0 || (format != RT_IMG_RGB8 && format != RT_IMG_PPM_P3 && format != RT_IMG_PPM_P6)) {
+    if (!hdr_rgb || !out_host || nx <= 0 || ny <= 0 || (format != RT_IMG_RGB8 && format != RT_IMG_PPM_P3 && format != RT_IMG_PPM_P6 && format != RT_IMG_EXR_HALF)) {
         c->error = "rt_image_encode: bad argument"; return RT_ERR_INVALID;
     }
     const int64_t npx = (int64_t)nx * ny;
@@ -726,6 +766,22 @@ int rt_image_encode(rt_ctx *c, const float *hdr_rgb, int nx, int ny, int hdr_on_
         HIP_TRY(c, c->d_img_in.ensure((size_t)npx * 3));
         HIP_TRY(c, hipMemcpyAsync(c->d_img_in.p, hdr_rgb, (size_t)npx * 3 * sizeof(float), hipMemcpyHostToDevice, s));
         d_hdr = c->d_img_in.p;
+    }
+    if (format == RT_IMG_EXR_HALF) {
+        const std::vector<unsigned char> prefix = exr_prefix(nx, ny);
+        const size_t body = (size_t)ny * (8 + 6 * (size_t)nx);
+        if (out_bytes) *out_bytes = prefix.size() + body;
+        if (out_capacity < prefix.size() + body) { c->error = "rt_image_encode: output buffer too small (see rt_image_encode_bound)"; return RT_ERR_INVALID; }
+        HIP_TRY(c, c->d_img_text.ensure(body + 16));
+        EventPair evx;
+        HIP_TRY(c, evx.start(ms_kernels != nullptr, s));
+        HIP_TRY(c, rt_img_exr_rows(s, d_hdr, nx, ny, c->d_img_text.p));
+        HIP_TRY(c, evx.stop(s));
+        std::memcpy(out_host, prefix.data(), prefix.size());
+        HIP_TRY(c, hipMemcpyAsync(static_cast<uint8_t *>(out_host) + prefix.size(), c->d_img_text.p, body, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (ms_kernels) *ms_kernels = evx.ms();
+        return RT_OK;
     }
     HIP_TRY(c, c->d_img8.ensure((size_t)npx * 3));
     char header[48];

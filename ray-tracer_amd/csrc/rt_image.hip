@@ -89,6 +89,51 @@ __global__ __launch_bounds__(IMG_BLOCK) void k_p3_write(const uint8_t *rgb, unsi
     }
 }
 
+// ---- EXR (half, uncompressed scan lines) ---------------------------------------------------------------------
+// tinyexr's float_to_half_full (reference src/tinyexr.h:7239-7274), bit for bit: truncation of the mantissa plus "round up
+// when the first dropped bit is set" (ties go away from zero, unlike the hardware's round-to-nearest-even conversion).
+__device__ __forceinline__ unsigned half_bits_tinyexr(float v) {
+    const unsigned f = __float_as_uint(v);
+    const unsigned sign = (f >> 16) & 0x8000u, exponent = (f >> 23) & 0xffu, mantissa = f & 0x7fffffu;
+    unsigned o = 0;
+    if (exponent == 0) o = 0;                                          // signed zero / denormal
+    else if (exponent == 255) o = (31u << 10) | (mantissa ? 0x200u : 0u);
+    else {
+        const int newexp = (int)exponent - 127 + 15;
+        if (newexp >= 31) o = 31u << 10;                               // overflow: infinity
+        else if (newexp <= 0) {
+            if ((14 - newexp) <= 24) {
+                const unsigned mant = mantissa | 0x800000u;
+                o = mant >> (14 - newexp);
+                if ((mant >> (13 - newexp)) & 1u) o++;
+            }
+        } else {
+            o = ((unsigned)newexp << 10) | (mantissa >> 13);
+            if (mantissa & 0x1000u) o++;
+        }
+    }
+    return (o & 0x7fffu) | sign;
+}
+
+// One scan-line block per image row (SaveEXRImageToMemory, tinyexr.h:12318-12449, compression NONE): int y, int data size,
+// then the row's B, G and R values as halfs, channel after channel (Tonemapper::SaveEXR names the channels B, G, R and
+// hands them over in that order, Tonemapper.cpp:57-74).  Rows are 8 + 6*nx bytes: every half is 2-byte aligned in `body`.
+__global__ __launch_bounds__(IMG_BLOCK) void k_exr_rows(const float *rgb, int nx, int ny, uint16_t *body) {
+    const int64_t i = (int64_t)blockIdx.x * IMG_BLOCK + threadIdx.x;
+    if (i >= (int64_t)nx * ny) return;
+    const int y = (int)(i / nx), x = (int)(i - (int64_t)y * nx);
+    uint16_t *row = body + (size_t)y * (4 + 3 * (size_t)nx);
+    if (x == 0) {
+        const unsigned len = 6u * (unsigned)nx;
+        row[0] = (uint16_t)((unsigned)y & 0xffffu); row[1] = (uint16_t)((unsigned)y >> 16);
+        row[2] = (uint16_t)(len & 0xffffu); row[3] = (uint16_t)(len >> 16);
+    }
+    const float *p = rgb + 3 * i;
+    row[4 + x] = (uint16_t)half_bits_tinyexr(p[2]);
+    row[4 + nx + x] = (uint16_t)half_bits_tinyexr(p[1]);
+    row[4 + 2 * (size_t)nx + x] = (uint16_t)half_bits_tinyexr(p[0]);
+}
+
 // ---- tone mapping ---------------------------------------------------------------------------------------
 // ComputeLuminance (DefaultTonemapStrategy.h:43-46); channels are 8-bit Colors converted to float in the reference.
 __device__ __forceinline__ float tm_lum(float r, float g, float b) { return 0.27f * r + 0.67f * g + 0.06f * b; }
@@ -191,6 +236,11 @@ hipError_t rt_img_p3_measure(hipStream_t s, const uint8_t *rgb, int64_t npx, int
 
 hipError_t rt_img_p3_write(hipStream_t s, const uint8_t *rgb, int64_t npx, int nx, const unsigned long long *block_off, uint8_t *out_body) {
     hipLaunchKernelGGL(k_p3_write, dim3((unsigned)rt_img_p3_blocks(npx)), dim3(IMG_BLOCK), 0, s, rgb, (unsigned)npx, (unsigned)nx, block_off, out_body);
+    return hipGetLastError();
+}
+
+hipError_t rt_img_exr_rows(hipStream_t s, const float *rgb, int nx, int ny, uint8_t *body) {
+    hipLaunchKernelGGL(k_exr_rows, dim3(blocks_for((int64_t)nx * ny)), dim3(IMG_BLOCK), 0, s, rgb, nx, ny, reinterpret_cast<uint16_t *>(body));
     return hipGetLastError();
 }
 

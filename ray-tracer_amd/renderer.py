@@ -252,8 +252,14 @@ class Mi355Renderer:
             hdr, pid, pt, st = self.ctx.render(i, seed=self.seed, timing=1)
             self.frames[cam["image_name"]] = hdr
             self.stats[cam["image_name"]] = st
-            with open(os.path.join(self.out_dir, cam["image_name"]), "wb") as f:      # Image::SaveImage without <Tonemap>
-                f.write(self.ctx.encode_image(hdr, abi.RT_IMG_PPM_P3).tobytes())
+            tm = getattr(scene, "tonemap", None)
+            if tm is None:                                                            # Image::SaveImage (Image.cpp:38-44)
+                data = self.ctx.encode_image(hdr, abi.RT_IMG_PPM_P3)
+            else:                                                                     # SaveImageAsEXR: tone map the 8-bit image, HALF EXR
+                mapped, _ = self.ctx.tonemap(hdr, tm[0], tm[1], tm[2], tm[3], input_8bit=True)
+                data = self.ctx.encode_image(mapped, abi.RT_IMG_EXR_HALF)
+            with open(os.path.join(self.out_dir, cam["image_name"]), "wb") as f:
+                f.write(data.tobytes())
 
     def close(self):
         self.ctx.close()

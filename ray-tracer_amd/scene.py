@@ -105,6 +105,7 @@ class SceneSoup:
         self.textures = np.zeros((0,), abi.texture_dtype)
         self.texels = np.zeros((0,), np.uint8)
         self.cameras = []                       # list of dicts (see camera_desc)
+        self.tonemap = None                     # (key, burn percent, saturation, gamma) of Scene::tmo, or None
         self.name = ""
 
     # ---- C view -------------------------------------------------------------------------
@@ -192,7 +193,8 @@ class SceneSoup:
             cams[i, 17] = c.get("focus_distance", 0.0)
             cams[i, 18] = c.get("aperture_size", 0.0)
         names = np.array([c.get("image_name", "") for c in self.cameras])
-        np.savez_compressed(path, params=np.array([self.max_depth, self.bg_texture], np.int64),
+        extra = {"tonemap": np.asarray(self.tonemap, np.float64)} if self.tonemap is not None else {}
+        np.savez_compressed(path, params=np.array([self.max_depth, self.bg_texture], np.int64), **extra,
                             eps=np.array([self.isect_eps, self.shadow_eps], F32), cameras=cams, camera_names=names,
                             **{k: getattr(self, k) for k in self._ARRAYS})
 
@@ -213,6 +215,8 @@ class SceneSoup:
                               "plane": row[9:13].astype(F32), "distance": F32(row[13]), "nx": int(row[14]), "ny": int(row[15]),
                               "num_samples": int(row[16]), "focus_distance": F32(row[17]), "aperture_size": F32(row[18]),
                               "image_name": str(nm)})
+        if "tonemap" in z.files:
+            s.tonemap = tuple(float(x) for x in z["tonemap"])
         s.name = os.path.splitext(os.path.basename(path))[0]
         s._contig()
         return s
@@ -524,6 +528,10 @@ def load_xml(path, scene_dir=None, texture_loader=None, perlin_tables=None):
         nx, ny = (int(x) for x in txt(cam, "ImageResolution").split())
         name = "".join(txt(cam, "ImageName").split())
         kw = dict(num_samples=ns, focus_distance=fd, aperture_size=ap, image_name=name)
+        tm = cam.find("Tonemap")
+        if tm is not None:                       # SceneParser.cpp:162-181: one scene-wide Tonemapper, the last camera's wins
+            key, burn = (float(x) for x in txt(tm, "TMOOptions").split()[:2])
+            s.tonemap = (key, burn, float(txt(tm, "Saturation")), float(txt(tm, "Gamma")))
         if cam.get("type") == "lookAt":
             b.add_lookat_camera(pos, _floats(txt(cam, "GazePoint")), up, float(txt(cam, "FovY")), dist, nx, ny, **kw)
         else:

@@ -145,3 +145,22 @@ def test_renderer_writes_ppm(rt, scene_path, tmp_path):
     img = np.array(toks[4:], np.int64).reshape(30, 40, 3)
     assert np.array_equal(img, rt.renderer.resolve_8bit(r.frames[name]))
     r.close()
+
+
+def test_renderer_with_tonemap_writes_exr(rt, orc, scene_path, tmp_path):
+    """A scene with <Tonemap> goes Image::SaveImageAsEXR's way: 8-bit image -> tone mapper -> HALF EXR under the image name
+    (Image.cpp:38-52).  The file is the oracle's EXR of the tone-mapped frame; the tone-mapped values themselves are checked
+    against the oracle's tone mapper (test_gpu_image.py states the tolerance)."""
+    soup = rt.SceneSoup.load(scene_path("cornellbox"))
+    soup.cameras[0]["nx"], soup.cameras[0]["ny"] = 64, 48
+    soup.tonemap = (0.18, 1.0, 1.0, 2.2)
+    r = rt.Mi355Renderer(0, out_dir=str(tmp_path))
+    r.RenderSceneIntoPPM(soup)
+    name = soup.cameras[0]["image_name"]
+    data = open(tmp_path / name, "rb").read()
+    mapped, params = r.ctx.tonemap(r.frames[name], 0.18, 1.0, 1.0, input_8bit=True)
+    assert data == orc.exr_half(mapped)
+    want, wparams = orc.tonemap(orc.resolve_8bit(r.frames[name]).astype(np.float32), 0.18, 1.0, 1.0)
+    ok = ~np.isnan(want)
+    assert params[1] == wparams[1] and np.allclose(mapped[ok], want[ok], rtol=1e-3, atol=1e-6)
+    r.close()

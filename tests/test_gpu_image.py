@@ -109,3 +109,21 @@ def test_tonemap_device_buffers_and_determinism(gpu_ctx):
     a, pa = gpu_ctx.tonemap(int(f.data_ptr()), 0.18, 1.0, 1.0, nx=480, ny=270)
     b, pb = gpu_ctx.tonemap(f.cpu().numpy(), 0.18, 1.0, 1.0)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(pa, pb)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 5), (7, 33), (270, 481)])
+def test_exr_half_file_equals_tinyexr_restatement(gpu_ctx, orc, shape):
+    """RT_IMG_EXR_HALF: header, offset table and scan-line blocks byte-identical to the oracle's restatement of
+    Tonemapper::SaveEXR + tinyexr (including tinyexr's own float->half rounding: ties away from zero, denormals, inf, NaN)."""
+    ny, nx = shape
+    rng = np.random.RandomState(nx)
+    f = (rng.rand(ny, nx, 3) ** 4 * 10.0).astype(np.float32)
+    special = np.array([0.0, -0.0, 1.0, 65504.0, 65520.0, 1e6, np.inf, -np.inf, np.nan, 6e-8, 5.96e-8, 2.98e-8, 6.1e-5, 1.0009765625,
+                        1.00048828125, 1.000732421875, -2.5, 1e-10], np.float32)      # ties, half denormals, overflow
+    k = min(f.size, special.size)
+    f.reshape(-1)[:k] = special[:k]
+    got = gpu_ctx.encode_image(f, abi.RT_IMG_EXR_HALF).tobytes()
+    want = orc.exr_half(f)
+    assert len(got) == len(want) == gpu_ctx.L.rt_image_encode_bound(nx, ny, abi.RT_IMG_EXR_HALF)
+    assert got == want
+    assert got[:4] == bytes([0x76, 0x2f, 0x31, 0x01])

@@ -206,3 +206,21 @@ def test_image_writer_and_tonemap_restatements(orc):
     res = reg * (1 + reg / (lw * lw)) / (1 + reg)
     want = (ch / lum[..., None]) ** 0.8 * res[..., None]
     assert np.allclose(out, want, rtol=1e-5)
+
+
+def test_exr_restatement_layout(orc):
+    """Known answers for the EXR writer restatement: magic / version, the attribute list in tinyexr's order, one offset per
+    row pointing at (y, 6*nx) block headers, halfs of exactly representable values, channel order B, G, R."""
+    import struct
+    f = np.array([[[1.0, 2.0, 0.5], [0.25, -1.0, 65504.0]]], np.float32)      # 1 row, 2 pixels
+    b = orc.exr_half(f)
+    assert b[:8] == bytes([0x76, 0x2f, 0x31, 0x01, 2, 0, 0, 0])
+    names = [b"channels\0chlist\0", b"compression\0compression\0", b"dataWindow\0box2i\0", b"displayWindow\0box2i\0",
+             b"lineOrder\0lineOrder\0", b"pixelAspectRatio\0float\0", b"screenWindowCenter\0v2f\0", b"screenWindowWidth\0float\0"]
+    pos = [b.find(n) for n in names]
+    assert all(p > 0 for p in pos) and pos == sorted(pos)
+    body = len(b) - (8 + 6 * 2)
+    assert struct.unpack_from("<Q", b, body - 8)[0] == body                   # the single offset-table entry
+    assert struct.unpack_from("<iI", b, body) == (0, 12)
+    halfs = np.frombuffer(b[body + 8:], np.float16)
+    assert halfs.tolist() == [0.5, 65504.0, 2.0, -1.0, 1.0, 0.25]             # B row, G row, R row
