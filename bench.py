@@ -152,7 +152,7 @@ def main():
                 "trace_ms_per_frame": round(trace_ms, 4)}
 
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:       # rank 0 at N=1 only
         from oracle import orc
         osc = orc.OracleScene(soup)
         cores = min(16, os.cpu_count() or 1)

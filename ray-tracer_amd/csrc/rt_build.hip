@@ -434,6 +434,7 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
     if (!bn.empty() || device_done)
         for (int k = 0; k < 3; ++k) scale = std::max(scale, std::max(std::fabs(hs.params.root_min[k]), std::fabs(hs.params.root_max[k])));
     hs.scene_scale = scale;
+    hs.params.prune_rel = 2e-4f;
     hs.params.prune_err = (4.0f * d->isect_eps + 2e-4f) * scale;   // eps*edge slack of the Cramer test + float error
     hs.info.n_nodes = (int64_t)bn.size(); hs.info.n_leaves = (int64_t)hs.leaves.size(); hs.info.max_depth = maxDepth; hs.info.n_wide_nodes = (int32_t)hs.nodes.size();
     hs.info.n_leaf_prims = (int64_t)hs.prims.size();

@@ -83,6 +83,7 @@ struct DevSceneParams {
     int32_t root;             // >= 0 DevNode4 index, < 0 leaf reference, RT_NO_ROOT when the scene is empty
     float root_min[3], root_max[3];
     float prune_err;          // absolute bound used to keep t-pruning conservative
+    float prune_rel;          // the same per unit of |origin|_1
     int32_t bvh_depth;        // depth of the reference (binary) tree
     int32_t stack_bound;      // most entries a traversal of the 4-wide tree can have on its stack
     int32_t tri_min_lanes;    // run the primitive path of the traversal once this many lanes of a wave wait in a leaf

@@ -416,7 +416,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                                 r = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                                 // a zero / denormal-range direction component (inf and NaN quotients): every fast test undecided
                                 amb = (fabsf(d.y) > 1e-30f && fabsf(d.z) > 1e-30f && fabsf(d.x) > 1e-30f) ? 1e-6f : __int_as_float(0x7f800000);
-                                const float err = sc.p.prune_err + 2e-4f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z));
+                                const float err = sc.p.prune_err + sc.p.prune_rel * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z));
                                 marg = mk3(err * fabsf(r.x) * 1.000001f, err * fabsf(r.y) * 1.000001f, err * fabsf(r.z) * 1.000001f);
                                 cur = sc.p.root;
                                 has_ray = true;

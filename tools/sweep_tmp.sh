@@ -1,1 +1,1 @@
-for t in 128 256 384 512 768 1024; do echo "block_cap $t"; RT_TRACE_BLOCK_CAP=$t RT_STREAMS=1 RT_SIZES=800x480,1600x960 timeout -k 10 100 python3 tools/trace_driver.py 3 2>&1 | tail -2 || exit 1; done
+for t in 1 0.3 0.1 0.01 0.001; do echo "prune_scale $t"; RT_COUNT=1 RT_PRUNE_SCALE=$t RT_STREAMS=1 RT_SIZES=800x480 timeout -k 10 100 python3 tools/trace_driver.py 3 2>&1 | tail -2 || exit 1; done

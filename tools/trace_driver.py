@@ -17,8 +17,9 @@ streams = [int(x) for x in os.environ.get("RT_STREAMS", "0").split(",")]
 sizes = [tuple(int(v) for v in x.split("x")) for x in os.environ.get("RT_SIZES", "800x480").split(",")]
 for ns in streams:
   for (nx, ny) in sizes:
-    if os.environ.get("RT_TRACE_DEBUG"):
-        ctx.render(0, want_ids=False, timing=2, num_streams=ns, nx=nx, ny=ny)   # counting frame: prints the lane-occupancy diagnostics
+    if os.environ.get("RT_TRACE_DEBUG") or os.environ.get("RT_COUNT"):
+        c = ctx.render(0, want_ids=False, timing=2, num_streams=ns, nx=nx, ny=ny)[3]   # counting frame (RT_TRACE_DEBUG: prints the lane-occupancy diagnostics)
+        print("counted: node steps %.2f, triangle tests %.2f per ray" % (c.node_visits / c.total_rays(), c.tri_tests / c.total_rays()))
     for _ in range(frames):
         hdr, _, _, st = ctx.render(0, want_ids=False, timing=1, num_streams=ns, nx=nx, ny=ny)
     print("size", nx, ny, "streams", ns, "rays", list(st.rays), "ms_total %.3f ms_kernels %.3f ms_trace(sum) %.3f busy %.3f launches %d" %
