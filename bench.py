@@ -83,6 +83,7 @@ def main():
     tg = mg.TileGather(nx, ny, TILE, rank, world, dev, torch)                    # compact owned pixels + frame, HBM resident
 
     def step(opts, stats):
+        tg.acquire()                                                              # the other of two tile buffers: frame i's gather may still run
         ctx.render_device(cd, opts, tg.tile_hdr.data_ptr(), None, None, stats)    # returns after the stream is idle
         # the only exchange step of the path: HDR tiles -> rank 0; point-to-point gather over xGMI
         tg.gather(dist)

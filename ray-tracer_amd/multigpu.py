@@ -19,7 +19,13 @@ class TileGather:
         L = renderer.library()
         self.counts = [int(L.rt_owned_pixel_count(nx, ny, tile_size, r, world)) for r in range(world)]
         self.max_owned = max(self.counts)
-        self.tile_hdr = torch.zeros((self.max_owned, 3), dtype=torch.float32, device=device)
+        # Two compact tile buffers: frame i+1 is rendered into one while the gather of frame i still reads the other
+        # (rt_render runs on the library's own stream; the gather is enqueued on torch's / RCCL's).  acquire() makes the
+        # re-use of a buffer wait for the gather that last read it.
+        self.buffers = [torch.zeros((self.max_owned, 3), dtype=torch.float32, device=device) for _ in range(2)]
+        self.events = [None, None]
+        self.cur = 0
+        self.tile_hdr = self.buffers[0]
         self.gathered = torch.zeros((world, self.max_owned, 3), dtype=torch.float32, device=device) if (world > 1 and rank == 0) else None
         self.frame = torch.zeros((ny * nx, 3), dtype=torch.float32, device=device) if rank == 0 else None
         self.orders = None
@@ -27,8 +33,26 @@ class TileGather:
             self.orders = [torch.from_numpy(renderer.tile_pixel_order(nx, ny, tile_size, r, world).astype(np.int64)).to(device)
                            for r in range(world)]
 
+    def acquire(self):
+        """The buffer the next frame is rendered into (self.tile_hdr), safe to overwrite."""
+        self.cur ^= 1
+        self.tile_hdr = self.buffers[self.cur]
+        if self.events[self.cur] is not None:
+            self.events[self.cur].synchronize()          # the gather that read this buffer two frames ago has finished
+        return self.tile_hdr
+
     def gather(self, dist=None):
-        """tile_hdr (this rank's compact pixels) -> rank 0's full frame [ny*nx, 3].  Returns the frame on rank 0."""
+        """tile_hdr (this rank's compact pixels) -> rank 0's full frame [ny*nx, 3].  Returns the frame on rank 0.  The work
+        is enqueued, not waited for (torch.cuda.synchronize() / the next acquire() of the same buffer do that)."""
+        try:
+            return self._gather(dist)
+        finally:
+            if self.tile_hdr.is_cuda:
+                ev = self.torch.cuda.Event()
+                ev.record()
+                self.events[self.cur] = ev
+
+    def _gather(self, dist=None):
         if self.world > 1:
             dist.gather(self.tile_hdr, list(self.gathered.unbind(0)) if self.rank == 0 else None, dst=0)
             if self.rank == 0:

@@ -24,10 +24,14 @@ WORKER = textwrap.dedent('''
     tg = mg.TileGather(nx, ny, tile, rank, world, torch.device("cpu"), torch)
     own = torch.from_numpy(rt.renderer.tile_pixel_order(nx, ny, tile, rank, world).astype(np.int64))
     assert len(own) == tg.counts[rank]
-    tg.tile_hdr[:len(own)] = full[own]            # what rt_render(compact_output=1) of this rank would have produced
-    frame = tg.gather(dist)
+    for it in range(3):                           # three frames through the two alternating tile buffers, like bench.py's loop
+        buf = tg.acquire()
+        assert buf is tg.tile_hdr and buf is tg.buffers[(it + 1) & 1]
+        buf[:len(own)] = full[own] * (it + 1)     # what rt_render(compact_output=1) of this rank would have produced
+        frame = tg.gather(dist)
+        if rank == 0:
+            assert torch.equal(frame, full * (it + 1)), "gathered frame differs"
     if rank == 0:
-        assert torch.equal(frame, full), "gathered frame differs"
         assert sum(tg.counts) == nx * ny
         print("GATHER_OK", tg.counts)
     dist.barrier()
