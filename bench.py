@@ -146,11 +146,26 @@ def main():
             traffic = json.load(open(tpath)).get("hbm_bytes_per_trace_launch")
         except Exception:
             traffic = None
+    # the same launch time priced with SURVEY 8(d)'s own yardstick: 64 B per node visit and per primitive test of a canonical
+    # binary, nearest-first, pruned traversal of the reference tree (counted by the CPU oracle, tests/golden/canonical_counts.json)
+    survey = None
+    cpath = os.path.join(ROOT, "tests", "golden", "canonical_counts.json")
+    ckey = "config2 dragon_standin_%d %dx%d" % (args.tris, nx, ny)
+    if os.path.exists(cpath):
+        try:
+            cc = json.load(open(cpath)).get(ckey)
+            if cc and cc["rays"] == int(n_rays) and world == 1:
+                sbytes = cc["bytes_per_ray"] * cc["rays"] / launches
+                survey = {"bytes_per_ray": round(cc["bytes_per_ray"], 1), "nodes_per_ray": round(cc["nodes"] / cc["rays"], 2),
+                          "tris_per_ray": round(cc["tris"] / cc["rays"], 2), "achieved": round(sbytes / (avg_launch_ms * 1e-3) / 1e9, 2),
+                          "frac": round(sbytes / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+        except Exception:
+            survey = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic, "kernel": "k_trace_generic (closest-hit rays of a level + shadow rays of the level before, one launch)", "launches_per_frame": launches,
                 "avg_launch_ms": round(avg_launch_ms, 5), "algorithmic_bytes_per_launch": round(bytes_per_launch),
                 "per_ray": {"nodes": round(n_node / n_rays, 2), "tris": round(n_tri / n_rays, 2), "bytes": round(frame_bytes / n_rays, 1)},
-                "trace_ms_per_frame": round(trace_ms, 4)}
+                "trace_ms_per_frame": round(trace_ms, 4), "survey_8d_formula": survey}
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:       # rank 0 at N=1 only

@@ -47,6 +47,7 @@ def lib():
         L.orc_ppm_p3.restype = C.c_size_t
         L.orc_exr_half.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         L.orc_exr_half.restype = C.c_size_t
+        L.orc_canonical_counts.argtypes = [C.c_void_p, C.POINTER(abi.CameraDesc), C.c_uint32, C.c_int, C.c_void_p]
         L.orc_abi_version.restype = C.c_uint32
         assert L.orc_abi_version() == abi.RT_ABI_VERSION
         _LIB = L
@@ -98,6 +99,15 @@ class OracleScene:
         if rc != 0:
             raise RuntimeError("orc_render rc=%d" % rc)
         return hdr, pid, pt, st
+
+    def canonical_counts(self, cam=0, seed=0, nthreads=8, **cam_override):
+        """{rays, nodes, tris, spheres} of the frame's rays through the canonical pruned traversal."""
+        cd = self.soup.camera_desc(cam, **cam_override) if not isinstance(cam, abi.CameraDesc) else cam
+        out = np.zeros(4, np.uint64)
+        rc = lib().orc_canonical_counts(self.h, C.byref(cd), seed, nthreads, out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("orc_canonical_counts rc=%d" % rc)
+        return {"rays": int(out[0]), "nodes": int(out[1]), "tris": int(out[2]), "spheres": int(out[3])}
 
     def intersect(self, rays):
         rays = np.ascontiguousarray(rays, abi.ray_dtype)

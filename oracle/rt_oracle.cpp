@@ -316,10 +316,12 @@ struct BVHNode {                                                                
 struct Counters {
     uint64_t rays[RT_RAY_KINDS];
     uint64_t box_tests, tri_tests, sphere_tests, node_visits;
+    uint64_t canon_nodes, canon_tris, canon_spheres;     // the canonical pruned traversal of SURVEY 8d (only when gCanonical is set)
     Counters() { std::memset(this, 0, sizeof(*this)); }
     void Add(const Counters &o) {
         for (int i = 0; i < RT_RAY_KINDS; ++i) rays[i] += o.rays[i];
         box_tests += o.box_tests; tri_tests += o.tri_tests; sphere_tests += o.sphere_tests; node_visits += o.node_visits;
+        canon_nodes += o.canon_nodes; canon_tris += o.canon_tris; canon_spheres += o.canon_spheres;
     }
 };
 
@@ -626,7 +628,45 @@ static void IntersectThroughHierarchy(const Scene &sc, BVHNode *head, Ray &r, Su
         }
     }
 }
+// The "canonical traversal" SURVEY 8d prices the algorithmic work with (NOT the reference's algorithm, a yardstick only):
+// stack based, nearer child first, subtrees skipped once their entry distance exceeds the best t + the 0.001 leaf margin,
+// over the reference-topology tree.  Counts node visits (one 64-byte node record each) and primitive tests.
+static std::atomic<bool> gCanonical(false);
+static void CanonicalCount(const Scene &sc, const Ray &ray, Counters &cnt) {
+    if (!sc.root) return;
+    struct Item { BVHNode *n; float tn; };
+    std::vector<Item> stack;
+    float tn, tf, best = std::numeric_limits<float>::max();
+    Ray r = ray;
+    if (!BoxIntersect(sc.root->bbox, r, tn, tf)) return;
+    stack.push_back(Item{sc.root, tn});
+    Counters scratch;
+    while (!stack.empty()) {
+        const Item it = stack.back();
+        stack.pop_back();
+        if (it.tn > best + 0.001f) continue;
+        ++cnt.canon_nodes;
+        if (it.n->IsLeaf()) {
+            for (int i = it.n->startIndex; i < it.n->endIndex; ++i) {
+                const Shape &sh = *sc.primitives[i]->shape;
+                if (sh.kind == SPHERE) ++cnt.canon_spheres; else ++cnt.canon_tris;
+                SurfaceIntersection t;
+                ShapeIntersect(sh, r, t, sc.d.isect_eps, scratch);
+                if (t.IsValid() && t.t > 0 && t.t < best) best = t.t;
+            }
+            continue;
+        }
+        float tl = 0, tr = 0;
+        const bool hl = BoxIntersect(it.n->left->bbox, r, tl, tf), hr = BoxIntersect(it.n->right->bbox, r, tr, tf);
+        if (hl && hr) {
+            if (tl <= tr) { stack.push_back(Item{it.n->right, tr}); stack.push_back(Item{it.n->left, tl}); }
+            else { stack.push_back(Item{it.n->left, tl}); stack.push_back(Item{it.n->right, tr}); }
+        } else if (hl) stack.push_back(Item{it.n->left, tl});
+        else if (hr) stack.push_back(Item{it.n->right, tr});
+    }
+}
 static inline void AccelIntersect(const Scene &sc, Ray &r, SurfaceIntersection &rt, Counters &cnt) {
+    if (gCanonical.load(std::memory_order_relaxed)) CanonicalCount(sc, r, cnt);
     IntersectThroughHierarchy(sc, sc.root, r, rt, sc.d.isect_eps, cnt);
 }
 
@@ -1410,6 +1450,37 @@ int orc_render(void *h, const rt_camera_desc *cam, uint32_t seed, int nthreads, 
         for (int i = 0; i < RT_RAY_KINDS; ++i) stats->rays[i] = total.rays[i];
         stats->node_visits = total.node_visits; stats->box_tests = total.box_tests; stats->tri_tests = total.tri_tests; stats->sphere_tests = total.sphere_tests;
     }
+    return 0;
+}
+
+// The frame's rays through the canonical traversal of SURVEY 8d: out = {rays, node visits, triangle tests, sphere tests}.
+int orc_canonical_counts(void *h, const rt_camera_desc *cam, uint32_t seed, int nthreads, uint64_t out[4]) {
+    orc::Scene *sc = static_cast<orc::Scene *>(h);
+    if (!sc || !cam || !out) return RT_ERR_INVALID;
+    if (nthreads < 1) nthreads = 1;
+    orc::Camera camera(*cam);
+    std::vector<orc::Counters> counters(nthreads);
+    std::atomic<int> nextRow(0);
+    orc::gCanonical.store(true);
+    auto work = [&](int tid) {
+        orc::Tracer tr(*sc);
+        float rgb[3];
+        for (;;) {
+            const int row = nextRow.fetch_add(1);
+            if (row >= cam->ny) break;
+            for (int col = 0; col < cam->nx; ++col) orc::RenderPixel(tr, camera, row, col, seed, rgb, nullptr, nullptr);
+        }
+        counters[tid] = tr.cnt;
+    };
+    std::vector<std::thread> threads;
+    for (int t = 0; t < nthreads; ++t) threads.emplace_back(work, t);
+    for (auto &t : threads) t.join();
+    orc::gCanonical.store(false);
+    orc::Counters total;
+    for (auto &c : counters) total.Add(c);
+    out[0] = 0;
+    for (int i = 0; i < RT_RAY_KINDS; ++i) out[0] += total.rays[i];
+    out[1] = total.canon_nodes; out[2] = total.canon_tris; out[3] = total.canon_spheres;
     return 0;
 }
 

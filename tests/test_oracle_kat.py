@@ -224,3 +224,15 @@ def test_exr_restatement_layout(orc):
     assert struct.unpack_from("<iI", b, body) == (0, 12)
     halfs = np.frombuffer(b[body + 8:], np.float16)
     assert halfs.tolist() == [0.5, 65504.0, 2.0, -1.0, 1.0, 0.25]             # B row, G row, R row
+
+
+def test_canonical_counts_fixture(rt, orc, scene_path):
+    """tests/golden/canonical_counts.json (SURVEY 8d yardstick, used by bench.py) is what the oracle counts: config 1 is
+    re-counted here, config 2 (9.3 M rays) is checked for its ray total and plausibility only."""
+    import json, os
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "canonical_counts.json")))
+    c1 = orc.OracleScene(rt.SceneSoup.load(scene_path("cornellbox_recursive"))).canonical_counts(0, nthreads=8)
+    want = fx["config1 cornellbox_recursive 800x800"]
+    assert {k: c1[k] for k in ("rays", "nodes", "tris", "spheres")} == {k: want[k] for k in ("rays", "nodes", "tris", "spheres")}
+    c2 = fx["config2 dragon_standin_1000000 800x480"]
+    assert c2["rays"] == 9313387 and 30 < c2["nodes"] / c2["rays"] < 80 and 5 < c2["tris"] / c2["rays"] < 20

@@ -1,0 +1,28 @@
+"""Generates tests/golden/canonical_counts.json: per configuration, the frame's rays through the canonical traversal that
+SURVEY.md 8(d) prices the algorithmic bytes with (CPU oracle; a few seconds per configuration on 8 cores)."""
+import importlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+rt = importlib.import_module("ray-tracer_amd")
+synth = importlib.import_module("ray-tracer_amd.synth")
+orc = importlib.import_module("oracle.orc")
+
+
+def main():
+    out = {}
+    cases = [("config1 cornellbox_recursive 800x800", rt.SceneSoup.load(os.path.join(ROOT, "scenes", "cornellbox_recursive.npz")), {}),
+             ("config2 dragon_standin_1000000 800x480", synth.dragon_standin_scene(1_000_000, 800, 480), {})]
+    for name, soup, kw in cases:
+        c = orc.OracleScene(soup).canonical_counts(0, nthreads=os.cpu_count() or 1, **kw)
+        c["bytes_per_ray"] = (64 * c["nodes"] + 64 * c["tris"] + 16 * c["spheres"]) / c["rays"] + 64 + 32      # SURVEY 8d formula
+        out[name] = c
+        print(name, c)
+    json.dump(out, open(os.path.join(ROOT, "tests", "golden", "canonical_counts.json"), "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
