@@ -175,7 +175,7 @@ typedef struct rt_render_opts {
     int32_t tile_world;       /* <=1: render every tile                                                */
     int32_t output_on_device; /* 1: hdr_rgb / prim_id / prim_t are DEVICE pointers (HBM-resident)      */
     int32_t compact_output;   /* 1: outputs hold only owned pixels, in rt_tile_pixel_order() order      */
-    int32_t max_batch_samples;/* samples traced per wavefront batch; <=0 selects the default (4M)      */
+    int32_t max_batch_samples;/* samples traced per wavefront batch; <=0 selects the default (8M)      */
     int32_t timing;           /* 1: bracket kernels with HIP events and fill rt_stats ms fields        */
     int32_t num_streams;      /* sub-batches in flight on separate HIP streams; <=0 selects the default (1), max 8 */
 } rt_render_opts;
