@@ -159,7 +159,7 @@ struct rt_ctx {
     DevArray<rt_hit> d_hits;
     int overflow_depth = 0;
     // frame post-processing (rt_image_encode, rt_tonemap)
-    DevArray<float> d_img_in, d_tm_lum, d_tm_sorted, d_tm_out, d_tm_params;
+    DevArray<float> d_img_in, d_tm_lum, d_tm_out, d_tm_params;
     DevArray<uint8_t> d_img8, d_img_text, d_img_tmp;
     DevArray<unsigned long long> d_img_len, d_img_off;
     DevArray<double> d_tm_partial;
@@ -174,7 +174,7 @@ static void release_all(rt_ctx *c) {
     c->d_pixels.release(); c->d_overflow.release();
     c->d_counts.release(); c->d_kind.release(); c->d_counters.release(); c->d_hdr.release(); c->d_pid.release(); c->d_pt.release();
     c->d_rays.release(); c->d_hits.release();
-    c->d_img_in.release(); c->d_tm_lum.release(); c->d_tm_sorted.release(); c->d_tm_out.release(); c->d_tm_params.release();
+    c->d_img_in.release(); c->d_tm_lum.release(); c->d_tm_out.release(); c->d_tm_params.release();
     c->d_img8.release(); c->d_img_text.release(); c->d_img_tmp.release(); c->d_img_len.release(); c->d_img_off.release(); c->d_tm_partial.release();
 }
 
@@ -841,18 +841,18 @@ int rt_tonemap(rt_ctx *c, const float *hdr_rgb, int nx, int ny, const rt_tonemap
     }
     float *d_out = out_rgb;
     if (!o->out_on_device) { HIP_TRY(c, c->d_tm_out.ensure((size_t)npx * 3)); d_out = c->d_tm_out.p; }
-    size_t sort_bytes = 0;
-    HIP_TRY(c, rt_img_sort_bytes(npx, &sort_bytes));
-    HIP_TRY(c, c->d_img_tmp.ensure(sort_bytes + 16));
-    HIP_TRY(c, c->d_tm_lum.ensure((size_t)npx)); HIP_TRY(c, c->d_tm_sorted.ensure((size_t)npx));
-    HIP_TRY(c, c->d_tm_partial.ensure((size_t)rt_img_p3_blocks(npx))); HIP_TRY(c, c->d_tm_params.ensure(2));
+    const size_t n_part = (size_t)rt_img_p3_blocks(npx);
+    HIP_TRY(c, c->d_tm_lum.ensure((size_t)npx));
+    HIP_TRY(c, c->d_tm_partial.ensure(n_part)); HIP_TRY(c, c->d_tm_params.ensure(2));
+    HIP_TRY(c, c->d_img_tmp.ensure((n_part + RT_TM_WORK_WORDS) * sizeof(unsigned)));
+    unsigned *d_pmax = reinterpret_cast<unsigned *>(c->d_img_tmp.p), *d_work = d_pmax + n_part;
     if (o->input_8bit) HIP_TRY(c, c->d_img8.ensure((size_t)npx * 3));
     EventPair ev;
     HIP_TRY(c, ev.start(ms_kernels != nullptr, s));
     const void *src = d_hdr;
     if (o->input_8bit) { HIP_TRY(c, rt_img_resolve8(s, d_hdr, npx * 3, c->d_img8.p)); src = c->d_img8.p; }   // the reference tone-maps its 8-bit Image (Q20)
-    HIP_TRY(c, rt_img_tonemap(s, src, o->input_8bit ? 1 : 0, npx, o->key, o->burn_percent, o->saturation, c->d_tm_lum.p, c->d_tm_sorted.p, c->d_tm_partial.p,
-                              c->d_tm_params.p, c->d_img_tmp.p, sort_bytes, d_out));
+    HIP_TRY(c, rt_img_tonemap(s, src, o->input_8bit ? 1 : 0, npx, o->key, o->burn_percent, o->saturation, c->d_tm_lum.p, c->d_tm_partial.p, d_pmax, d_work,
+                              c->d_tm_params.p, d_out));
     HIP_TRY(c, ev.stop(s));
     if (!o->out_on_device) HIP_TRY(c, hipMemcpyAsync(out_rgb, d_out, (size_t)npx * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
     if (out_params) HIP_TRY(c, hipMemcpyAsync(out_params, c->d_tm_params.p, 2 * sizeof(float), hipMemcpyDeviceToHost, s));

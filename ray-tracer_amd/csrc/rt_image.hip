@@ -144,43 +144,101 @@ __device__ __forceinline__ void tm_load(const void *src, int64_t i, float &r, fl
     else { const float *p = static_cast<const float *>(src) + 3 * i; r = p[0]; g = p[1]; b = p[2]; }
 }
 
+// Order-preserving map float -> unsigned (the order a radix sort of floats uses: -NaN < -inf < ... < -0 < +0 < ... < +inf < NaN).
+__device__ __forceinline__ unsigned tm_key(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float tm_unkey(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
 // RecordPixelLuminance (:64-71): the luminance of every pixel and log(luminance + 0.00001f) in double (the unqualified
-// `log` there is ::log(double)); partial sums per block, in a fixed order.
+// `log` there is ::log(double)); partial sums and the largest luminance per block, in a fixed order.
 template <bool FROM8>
-__global__ __launch_bounds__(IMG_BLOCK) void k_tm_lum(const void *src, int64_t npx, float *lum, double *partial) {
+__global__ __launch_bounds__(IMG_BLOCK) void k_tm_lum(const void *src, int64_t npx, float *lum, double *partial, unsigned *partial_max) {
     using Reduce = hipcub::BlockReduce<double, IMG_BLOCK>;
+    using ReduceU = hipcub::BlockReduce<unsigned, IMG_BLOCK>;
     __shared__ typename Reduce::TempStorage tmp;
+    __shared__ typename ReduceU::TempStorage tmpu;
     const int64_t i = (int64_t)blockIdx.x * IMG_BLOCK + threadIdx.x;
     double lg = 0.0;
+    unsigned k = 0;
     if (i < npx) {
         float r, g, b;
         tm_load<FROM8>(src, i, r, g, b);
         const float l = tm_lum(r, g, b);
         lum[i] = l;
         lg = log((double)(l + 0.00001f));
+        k = tm_key(l);
     }
     const double sum = Reduce(tmp).Sum(lg);
-    if (threadIdx.x == 0) partial[blockIdx.x] = sum;
+    const unsigned mx = ReduceU(tmpu).Reduce(k, hipcub::Max());
+    if (threadIdx.x == 0) { partial[blockIdx.x] = sum; partial_max[blockIdx.x] = mx; }
 }
 
-// SetupGeneralAttributes (:37-46) + ComputeLuminanceWhite (:104-107) on the sorted luminances.
-// params: [0] average luminance, [1] luminance white.
-__global__ __launch_bounds__(IMG_BLOCK) void k_tm_params(const double *partial, int n_partial, const float *sorted, int64_t npx, float burn_percent, float *params) {
+// HeapifyLuminanceVector (:73-77) sorts all luminances, ComputeLuminanceWhite (:104-107) then reads ONE of them and the
+// largest.  Here: a three-pass radix SELECT of that one element (11 + 11 + 10 bits of the order-preserving key; per pass a
+// histogram of the candidates that still match the prefix, then the bin holding the wanted rank), 4 bytes per pixel and
+// pass instead of the ~64 bytes per pixel of a full radix sort.  sel: [0] key prefix found so far, [1] rank inside it.
+constexpr int TM_BINS = 2048;
+template <int PASS>
+__global__ __launch_bounds__(IMG_BLOCK) void k_tm_hist(const float *lum, int64_t npx, const unsigned *sel, unsigned *hist) {
+    __shared__ unsigned h[TM_BINS];
+    for (int b = threadIdx.x; b < TM_BINS; b += IMG_BLOCK) h[b] = 0;
+    __syncthreads();
+    const unsigned prefix = sel[0];
+    for (int64_t i = (int64_t)blockIdx.x * IMG_BLOCK + threadIdx.x; i < npx; i += (int64_t)gridDim.x * IMG_BLOCK) {
+        const unsigned k = tm_key(lum[i]);
+        if (PASS == 0) atomicAdd(&h[k >> 21], 1u);
+        else if (PASS == 1) { if ((k >> 21) == (prefix >> 21)) atomicAdd(&h[(k >> 10) & 2047u], 1u); }
+        else { if ((k >> 10) == (prefix >> 10)) atomicAdd(&h[k & 1023u], 1u); }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < TM_BINS; b += IMG_BLOCK) if (h[b]) atomicAdd(&hist[b], h[b]);
+}
+
+__global__ void k_tm_init(unsigned *work, unsigned rank) {          // select state {prefix 0, rank} and a cleared histogram
+    for (int i = threadIdx.x; i < RT_TM_WORK_WORDS; i += blockDim.x) work[i] = i == 1 ? rank : 0u;
+}
+
+// The bin that holds rank sel[1]; clears the histogram for the next pass.
+template <int PASS>
+__global__ __launch_bounds__(IMG_BLOCK) void k_tm_pick(unsigned *hist, unsigned *sel) {
+    using Scan = hipcub::BlockScan<unsigned, IMG_BLOCK>;
+    __shared__ typename Scan::TempStorage tmp;
+    constexpr int PER = TM_BINS / IMG_BLOCK;
+    unsigned v[PER], sum = 0;
+    for (int j = 0; j < PER; ++j) { v[j] = hist[threadIdx.x * PER + j]; sum += v[j]; hist[threadIdx.x * PER + j] = 0; }
+    unsigned before;
+    Scan(tmp).ExclusiveSum(sum, before);
+    const unsigned rank = sel[1];
+    __syncthreads();                                                  // every thread has read the rank before one rewrites it
+    if (rank >= before && rank < before + sum) {
+        unsigned acc = before;
+        for (int j = 0; j < PER; ++j) {
+            if (rank < acc + v[j]) {
+                const unsigned bin = threadIdx.x * PER + j;
+                sel[0] = PASS == 0 ? bin << 21 : (PASS == 1 ? (sel[0] | (bin << 10)) : (sel[0] | bin));
+                sel[1] = rank - acc;
+                break;
+            }
+            acc += v[j];
+        }
+    }
+}
+
+// SetupGeneralAttributes (:37-46) + ComputeLuminanceWhite (:104-107).  params: [0] average luminance, [1] luminance white.
+__global__ __launch_bounds__(IMG_BLOCK) void k_tm_params(const double *partial, const unsigned *partial_max, int n_partial, const unsigned *sel, int64_t npx, float *params) {
     using Reduce = hipcub::BlockReduce<double, IMG_BLOCK>;
+    using ReduceU = hipcub::BlockReduce<unsigned, IMG_BLOCK>;
     __shared__ typename Reduce::TempStorage tmp;
+    __shared__ typename ReduceU::TempStorage tmpu;
     double acc = 0.0;
-    for (int i = threadIdx.x; i < n_partial; i += IMG_BLOCK) acc += partial[i];
+    unsigned mx = 0;
+    for (int i = threadIdx.x; i < n_partial; i += IMG_BLOCK) { acc += partial[i]; mx = partial_max[i] > mx ? partial_max[i] : mx; }
     const double sum = Reduce(tmp).Sum(acc);
+    mx = ReduceU(tmpu).Reduce(mx, hipcub::Max());
     if (threadIdx.x != 0) return;
     float s = (float)sum;
     s = s / (float)npx;                                               // luminanceSum /= GetImageSize()
     params[0] = (float)exp((double)s);
-    const float pos = (float)npx * (100.f - burn_percent) / 100.f;
-    double ri = round((double)pos);
-    if (!(ri >= 0.0)) ri = 0.0;                                       // outside [0, n) the reference indexes out of bounds
-    int64_t idx = (int64_t)ri;
-    if (idx > npx - 1) idx = npx - 1;
-    params[1] = sorted[idx] / sorted[npx - 1];
+    params[1] = tm_unkey(sel[0]) / tm_unkey(mx);                      // mLuminances[rank] / mLuminances.back()
 }
 
 // ComputeTonemappedPixelColor (:79-102).
@@ -244,21 +302,31 @@ hipError_t rt_img_exr_rows(hipStream_t s, const float *rgb, int nx, int ny, uint
     return hipGetLastError();
 }
 
-hipError_t rt_img_sort_bytes(int64_t npx, size_t *bytes) {
-    *bytes = 0;
-    return hipcub::DeviceRadixSort::SortKeys(nullptr, *bytes, (const float *)nullptr, (float *)nullptr, (int)npx);
+// The rank ComputeLuminanceWhite reads (:106): round(size * (100.f - percentage) / 100.f) in the reference's float
+// arithmetic; outside [0, n) the reference indexes out of bounds, clamped here.
+static int64_t tm_rank(int64_t npx, float burn_percent) {
+    const float pos = (float)npx * (100.f - burn_percent) / 100.f;
+    double ri = round((double)pos);
+    if (!(ri >= 0.0)) ri = 0.0;
+    int64_t idx = (int64_t)ri;
+    return idx > npx - 1 ? npx - 1 : idx;
 }
 
+// work: TM_WORK_WORDS unsigned words (select state + histogram); partial / partial_max: one entry per 256 pixels.
 hipError_t rt_img_tonemap(hipStream_t s, const void *src, int from8, int64_t npx, float key, float burn_percent, float saturation,
-                          float *lum, float *sorted, double *partial, float *params, void *sort_tmp, size_t sort_bytes, float *out) {
-    const unsigned nb = blocks_for(npx);
-    if (from8) hipLaunchKernelGGL(k_tm_lum<true>, dim3(nb), dim3(IMG_BLOCK), 0, s, src, npx, lum, partial);
-    else hipLaunchKernelGGL(k_tm_lum<false>, dim3(nb), dim3(IMG_BLOCK), 0, s, src, npx, lum, partial);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    // HeapifyLuminanceVector (:73-77) is an ascending sort
-    if ((e = hipcub::DeviceRadixSort::SortKeys(sort_tmp, sort_bytes, (const float *)lum, sorted, (int)npx, 0, 32, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_tm_params, dim3(1), dim3(IMG_BLOCK), 0, s, partial, (int)nb, sorted, npx, burn_percent, params);
+                          float *lum, double *partial, unsigned *partial_max, unsigned *work, float *params, float *out) {
+    const unsigned nb = blocks_for(npx), nh = nb < 2048u ? nb : 2048u;
+    unsigned *sel = work, *hist = work + 4;
+    hipLaunchKernelGGL(k_tm_init, dim3(1), dim3(IMG_BLOCK), 0, s, work, (unsigned)tm_rank(npx, burn_percent));
+    if (from8) hipLaunchKernelGGL(k_tm_lum<true>, dim3(nb), dim3(IMG_BLOCK), 0, s, src, npx, lum, partial, partial_max);
+    else hipLaunchKernelGGL(k_tm_lum<false>, dim3(nb), dim3(IMG_BLOCK), 0, s, src, npx, lum, partial, partial_max);
+    hipLaunchKernelGGL(k_tm_hist<0>, dim3(nh), dim3(IMG_BLOCK), 0, s, lum, npx, sel, hist);
+    hipLaunchKernelGGL(k_tm_pick<0>, dim3(1), dim3(IMG_BLOCK), 0, s, hist, sel);
+    hipLaunchKernelGGL(k_tm_hist<1>, dim3(nh), dim3(IMG_BLOCK), 0, s, lum, npx, sel, hist);
+    hipLaunchKernelGGL(k_tm_pick<1>, dim3(1), dim3(IMG_BLOCK), 0, s, hist, sel);
+    hipLaunchKernelGGL(k_tm_hist<2>, dim3(nh), dim3(IMG_BLOCK), 0, s, lum, npx, sel, hist);
+    hipLaunchKernelGGL(k_tm_pick<2>, dim3(1), dim3(IMG_BLOCK), 0, s, hist, sel);
+    hipLaunchKernelGGL(k_tm_params, dim3(1), dim3(IMG_BLOCK), 0, s, partial, partial_max, (int)nb, sel, npx, params);
     if (from8) hipLaunchKernelGGL(k_tm_apply<true>, dim3(nb), dim3(IMG_BLOCK), 0, s, src, npx, params, key, saturation, out);
     else hipLaunchKernelGGL(k_tm_apply<false>, dim3(nb), dim3(IMG_BLOCK), 0, s, src, npx, params, key, saturation, out);
     return hipGetLastError();

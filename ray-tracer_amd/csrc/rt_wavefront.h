@@ -97,8 +97,8 @@ hipError_t rt_img_p3_measure(hipStream_t s, const uint8_t *rgb, int64_t npx, int
                              void *scan_tmp, size_t scan_bytes);
 hipError_t rt_img_p3_write(hipStream_t s, const uint8_t *rgb, int64_t npx, int nx, const unsigned long long *block_off, uint8_t *out_body);
 hipError_t rt_img_exr_rows(hipStream_t s, const float *rgb, int nx, int ny, uint8_t *body);   // body: ny * (8 + 6 nx) bytes, 2-byte aligned
-hipError_t rt_img_sort_bytes(int64_t npx, size_t *bytes);
+#define RT_TM_WORK_WORDS (4 + 2048)   // select state + histogram of rt_img_tonemap
 hipError_t rt_img_tonemap(hipStream_t s, const void *src, int from8, int64_t npx, float key, float burn_percent, float saturation,
-                          float *lum, float *sorted, double *partial, float *params, void *sort_tmp, size_t sort_bytes, float *out);
+                          float *lum, double *partial, unsigned *partial_max, unsigned *work, float *params, float *out);
 
 #endif

@@ -31,8 +31,8 @@ def main():
         npx = nx * ny
         # algorithmic bytes: resolve reads 12 B/px, writes 3; measure + write read the 8-bit image once each; text written once
         p3_bytes = npx * (12 + 3 + 3 + 3) + nbytes
-        # tone mapping (8-bit input): resolve 12+3, luminance 3+4, sort 4 passes x (4+4), apply 3+12
-        tm_bytes = npx * (12 + 3 + 3 + 4 + 4 * 8 + 3 + 12)
+        # tone mapping (8-bit input): resolve 12+3, luminance 3+4, three select passes x 4, apply 3+12
+        tm_bytes = npx * (12 + 3 + 3 + 4 + 3 * 4 + 3 + 12)
         host = f.cpu().numpy()
         img8 = orc.resolve_8bit(host)
         t0 = time.perf_counter(); txt = orc.ppm_p3(img8); t1 = time.perf_counter()
