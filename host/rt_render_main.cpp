@@ -1,0 +1,53 @@
+// rt_render — the reference's main (src/main.cpp:15-30) over the MI355X path, in the reference's language:
+//   parse the scene (here: the flat scene file, host/scene_file.h), create the renderer, RenderSceneIntoPPM, report the time.
+// usage: rt_render <scene.rtscene> [out_dir] [--rays <rays.bin> <hits.bin>]
+//   --rays: also answer a batch of AccelerationStructure::Intersect queries (rt_ray records in, rt_hit records out).
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "scene_file.h"
+
+int main(int argc, char **argv) {
+    if (argc < 2) { std::fprintf(stderr, "usage: %s <scene.rtscene> [out_dir] [--rays rays.bin hits.bin]\n", argv[0]); return 2; }
+    try {
+        rt_mi355::LoadedScene scene;
+        rt_mi355::LoadScene(argv[1], scene);
+        std::string out_dir = ".";
+        const char *rays_path = nullptr, *hits_path = nullptr;
+        for (int i = 2; i < argc; ++i) {
+            if (!std::strcmp(argv[i], "--rays") && i + 2 < argc) { rays_path = argv[i + 1]; hits_path = argv[i + 2]; i += 2; }
+            else out_dir = argv[i];
+        }
+        rt_mi355::Mi355Renderer renderer(0, out_dir);                   // main.cpp:20  new DefaultRenderer()
+        const auto t0 = std::chrono::steady_clock::now();
+        renderer.RenderSceneIntoPPM(scene.view);                          // main.cpp:22
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        const rt_bvh_info info = renderer.context().BvhInfo();
+        std::printf("rendered %zu camera(s) of %s in %.1f ms (upload incl.; %lld BVH nodes, depth %d)\n", scene.view.cameras.size(), argv[1], ms,
+                    (long long)info.n_nodes, info.max_depth);
+        if (rays_path) {
+            FILE *f = std::fopen(rays_path, "rb");
+            if (!f) throw rt_mi355::Error(RT_ERR_INVALID, std::string("cannot open ") + rays_path);
+            std::fseek(f, 0, SEEK_END);
+            const long bytes = std::ftell(f);
+            std::fseek(f, 0, SEEK_SET);
+            std::vector<rt_ray> rays((size_t)bytes / sizeof(rt_ray));
+            if (std::fread(rays.data(), sizeof(rt_ray), rays.size(), f) != rays.size()) { std::fclose(f); throw rt_mi355::Error(RT_ERR_INVALID, "short read"); }
+            std::fclose(f);
+            std::vector<rt_hit> hits(rays.size());
+            rt_mi355::Mi355Accelerator accel(scene.view);                 // AccelerationStructureFactory::CreateAccelerationStructure
+            accel.Intersect(rays.data(), rays.size(), hits.data());
+            f = std::fopen(hits_path, "wb");
+            if (!f || std::fwrite(hits.data(), sizeof(rt_hit), hits.size(), f) != hits.size()) throw rt_mi355::Error(RT_ERR_INVALID, std::string("cannot write ") + hits_path);
+            std::fclose(f);
+            std::printf("answered %zu intersection queries\n", rays.size());
+        }
+    } catch (const rt_mi355::Error &e) {
+        std::fprintf(stderr, "%s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,125 @@
+// rt_mi355.hpp — C++11 host side over the C-ABI of librt_mi355.so (include/rt_mi355.h), header only.
+//
+// The reference's host is C++ (src/main.cpp:15-30: parse a scene, `new DefaultRenderer()`, RenderSceneIntoPPM, delete), so
+// this is the same shape in the same language: two classes with the names and call signatures of the reference's plugin
+// interfaces, working on a flattened scene (SceneView: the content of the reference's `Scene` after parsing) instead of the
+// reference's own class graph, which cannot be linked here (INTEGRATION.md shows the subclass a maintainer adds on top).
+//
+//   rt_mi355::Mi355Renderer      <->  RenderStrategy        (src/RenderStrategy.h:12-26, DefaultRenderer.cpp:35-162)
+//   rt_mi355::Mi355Accelerator   <->  AccelerationStructure (src/AccelerationStructure.h:12-26, BVHTree.cpp:155-206)
+//
+// Errors: the reference's interfaces return void and never report anything; here every failed ABI call throws
+// rt_mi355::Error (code = rt_status, what() = rt_last_error).  There is no CPU fallback.
+#ifndef RT_MI355_HPP_
+#define RT_MI355_HPP_
+
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "rt_mi355.h"
+
+namespace rt_mi355 {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &msg) : std::runtime_error("rt_mi355 error " + std::to_string(c) + ": " + msg), code(c) {}
+};
+
+struct CameraView {
+    rt_camera_desc desc;
+    std::string image_name;          // Camera::GetImageName()
+};
+
+// What the reference's Scene holds after parsing: the description arrays, the cameras and the optional <Tonemap>.
+struct SceneView {
+    rt_scene_desc desc;
+    std::vector<CameraView> cameras;
+    bool has_tonemap = false;
+    float tonemap[4] = {0, 0, 0, 0}; // key, burn percent, saturation, gamma (SceneParser.cpp:162-181)
+};
+
+class Context {
+public:
+    explicit Context(int hip_device = 0) { const int rc = rt_ctx_create(hip_device, &h_); if (rc != RT_OK) throw Error(rc, rt_last_error(nullptr)); }
+    ~Context() { rt_ctx_destroy(h_); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+
+    void Upload(const rt_scene_desc &scene) { Check(rt_scene_upload(h_, &scene)); }
+    rt_bvh_info BvhInfo() const { rt_bvh_info i; Check(rt_scene_bvh_info(h_, &i)); return i; }
+
+    // float frame [ny*nx*3] on the host
+    std::vector<float> Render(const rt_camera_desc &cam, unsigned seed = 0, rt_stats *stats = nullptr) {
+        rt_render_opts o = rt_render_opts();
+        o.abi_version = RT_ABI_VERSION; o.seed = seed; o.timing = stats ? 1 : 0;
+        std::vector<float> hdr((size_t)3 * cam.nx * cam.ny);
+        Check(rt_render(h_, &cam, &o, hdr.data(), nullptr, nullptr, stats));
+        return hdr;
+    }
+    void Intersect(const rt_ray *rays, size_t n, rt_hit *hits) const { Check(rt_intersect_batch(h_, rays, n, hits, 0, nullptr)); }
+
+    std::vector<unsigned char> EncodeImage(const float *rgb, int nx, int ny, int format) {
+        std::vector<unsigned char> out(rt_image_encode_bound(nx, ny, format));
+        size_t n = 0;
+        Check(rt_image_encode(h_, rgb, nx, ny, 0, format, out.data(), out.size(), &n, nullptr));
+        out.resize(n);
+        return out;
+    }
+    std::vector<float> Tonemap(const float *rgb, int nx, int ny, const float tm[4], bool input_8bit = true) {
+        rt_tonemap_opts o = rt_tonemap_opts();
+        o.abi_version = RT_ABI_VERSION; o.key = tm[0]; o.burn_percent = tm[1]; o.saturation = tm[2]; o.gamma = tm[3]; o.input_8bit = input_8bit ? 1 : 0;
+        std::vector<float> out((size_t)3 * nx * ny);
+        Check(rt_tonemap(h_, rgb, nx, ny, &o, out.data(), nullptr, nullptr));
+        return out;
+    }
+    rt_ctx *handle() const { return h_; }
+
+private:
+    void Check(int rc) const { if (rc != RT_OK) throw Error(rc, rt_last_error(h_)); }
+    rt_ctx *h_ = nullptr;
+};
+
+// AccelerationStructure: built from a scene's primitives, answers closest-hit queries.  The reference takes one ray per
+// call; a GPU needs batches, so Intersect takes n rays ("no hit" is shape == -1 where the reference has mat == nullptr).
+class Mi355Accelerator {
+public:
+    explicit Mi355Accelerator(const SceneView &scene, int hip_device = 0) : ctx_(hip_device) { ctx_.Upload(scene.desc); }
+    void Intersect(const rt_ray *rays, size_t n, rt_hit *out) const { ctx_.Intersect(rays, n, out); }
+    void Intersect(const rt_ray &ray, rt_hit &out) const { ctx_.Intersect(&ray, 1, &out); }      // drop-in form: one launch per ray
+private:
+    Context ctx_;
+};
+
+// RenderStrategy: RenderSceneIntoPPM renders every camera of the scene and writes camera.image_name — the P3 text of
+// Image::SaveImageAsPPM, or with <Tonemap> the tone-mapped frame as HALF EXR (Image::SaveImage, src/Image.cpp:38-52).
+class Mi355Renderer {
+public:
+    explicit Mi355Renderer(int hip_device = 0, const std::string &out_dir = ".") : ctx_(hip_device), out_dir_(out_dir) {}
+    void RenderSceneIntoPPM(const SceneView &scene) {
+        ctx_.Upload(scene.desc);                                   // RetrieveRenderingParamsFromScene: builds the accelerator
+        for (const CameraView &cam : scene.cameras) {
+            const std::vector<float> hdr = ctx_.Render(cam.desc);
+            std::vector<unsigned char> file;
+            if (!scene.has_tonemap) file = ctx_.EncodeImage(hdr.data(), cam.desc.nx, cam.desc.ny, RT_IMG_PPM_P3);
+            else {
+                const std::vector<float> mapped = ctx_.Tonemap(hdr.data(), cam.desc.nx, cam.desc.ny, scene.tonemap);
+                file = ctx_.EncodeImage(mapped.data(), cam.desc.nx, cam.desc.ny, RT_IMG_EXR_HALF);
+            }
+            const std::string path = out_dir_ + "/" + cam.image_name;
+            FILE *f = std::fopen(path.c_str(), "wb");
+            if (!f) throw Error(RT_ERR_INVALID, "cannot open " + path);
+            const size_t w = std::fwrite(file.data(), 1, file.size(), f);
+            std::fclose(f);
+            if (w != file.size()) throw Error(RT_ERR_INVALID, "short write to " + path);
+        }
+    }
+    Context &context() { return ctx_; }
+private:
+    Context ctx_;
+    std::string out_dir_;
+};
+
+}  // namespace rt_mi355
+#endif

@@ -198,6 +198,31 @@ class SceneSoup:
                             eps=np.array([self.isect_eps, self.shadow_eps], F32), cameras=cams, camera_names=names,
                             **{k: getattr(self, k) for k in self._ARRAYS})
 
+    def save_raw(self, path):
+        """The flat scene file the C++ host reads (host/scene_file.h): header, the twelve description arrays, cameras."""
+        import ctypes
+        import struct
+        self._contig()
+        tm = self.tonemap
+        with open(path, "wb") as f:
+            f.write(b"RTSCENE1")
+            f.write(struct.pack("<i2f3f3fii4f", int(self.max_depth), float(self.isect_eps), float(self.shadow_eps),
+                                *[float(x) for x in self.background], *[float(x) for x in self.ambient], int(self.bg_texture),
+                                1 if tm is not None else 0, *([float(x) for x in tm] if tm is not None else [0.0] * 4)))
+            for arr, n in ((self.vert_pos, len(self.vert_pos)), (self.vert_uv, len(self.vert_uv)), (self.tri_vert, len(self.tri_vert)),
+                           (self.tri_object, len(self.tri_object)), (self.sph_center_radius, len(self.sph_center_radius)),
+                           (self.sph_object, len(self.sph_object)), (self.objects, len(self.objects)), (self.prim_shape, len(self.prim_shape)),
+                           (self.materials, len(self.materials)), (self.lights, len(self.lights)), (self.textures, len(self.textures)),
+                           (self.texels, len(self.texels))):
+                f.write(struct.pack("<Q", n))
+                f.write(arr.tobytes())
+            f.write(struct.pack("<Q", len(self.cameras)))
+            for i, c in enumerate(self.cameras):
+                name = c.get("image_name", "out.ppm").encode()
+                f.write(ctypes.string_at(ctypes.byref(self.camera_desc(i)), ctypes.sizeof(abi.CameraDesc)))
+                f.write(struct.pack("<I", len(name)))
+                f.write(name)
+
     @staticmethod
     def load(path):
         z = np.load(path, allow_pickle=False)
