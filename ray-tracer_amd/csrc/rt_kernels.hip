@@ -1318,7 +1318,7 @@ __global__ __launch_bounds__(256) void k_count_kinds(LevelBuf lv, int n, const i
     }
 }
 void rt_launch_shade_pre(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, ShadowBuf sb, LevelBuf next, int depth,
-                         int *next_count, unsigned long long *kind_counts) {
+                         int *next_count) {
     if (n <= 0) return;
     const dim3 g((n + 255) / 256), b(256);
     const bool ntex = sc.p.has_normal_tex != 0, rng = sc.p.has_rng != 0;
@@ -1326,7 +1326,12 @@ void rt_launch_shade_pre(hipStream_t s, const DevScene &sc, const DevCamera &cam
     else if (ntex) hipLaunchKernelGGL((k_shade_pre<true, false>), g, b, 0, s, sc, cam, lv, n, sb, next, depth, next_count);
     else if (rng) hipLaunchKernelGGL((k_shade_pre<false, true>), g, b, 0, s, sc, cam, lv, n, sb, next, depth, next_count);
     else hipLaunchKernelGGL((k_shade_pre<false, false>), g, b, 0, s, sc, cam, lv, n, sb, next, depth, next_count);
-    if (kind_counts) hipLaunchKernelGGL(k_count_kinds, dim3(std::min((n + 255) / 256, 512)), dim3(256), 0, s, lv, n, sb.count, kind_counts);
+}
+// rays per kind of a level after its surface pass (statistics only; a launch of its own so that the host can queue it behind
+// the copy of the child count)
+void rt_launch_count_kinds(hipStream_t s, LevelBuf lv, int n, ShadowBuf sb, unsigned long long *kind_counts) {
+    if (n <= 0 || !kind_counts) return;
+    hipLaunchKernelGGL(k_count_kinds, dim3(std::min((n + 255) / 256, 512)), dim3(256), 0, s, lv, n, sb.count, kind_counts);
 }
 
 // After the shadow rays of the level are traced: the local colour of every hit (ProcessLights, LightContributionCalculator.cpp:98-124),

@@ -80,7 +80,8 @@ void rt_launch_trace(hipStream_t s, const DevScene &sc, LevelBuf lv, int n_close
                      int *overflow_stack, DevCounters *counters);
 void rt_launch_trace_batch(hipStream_t s, const DevScene &sc, const rt_ray *rays, rt_hit *hits, int n, int *fetch_counter, int *overflow_stack, DevCounters *counters);
 void rt_launch_shade_pre(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, ShadowBuf sb, LevelBuf next, int depth,
-                         int *next_count, unsigned long long *ray_kind_counts);
+                         int *next_count);
+void rt_launch_count_kinds(hipStream_t s, LevelBuf lv, int n, ShadowBuf sb, unsigned long long *ray_kind_counts);
 void rt_launch_shade_post(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, ShadowBuf sb);
 void rt_launch_backward(hipStream_t s, LevelBuf lv, int n, LevelBuf next, int has_next);
 void rt_launch_resolve(hipStream_t s, const DevCamera &cam, const int *pixel_list, int first_pixel, int n_pixels, LevelBuf lv0, int compact,
