@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, L
                                                    int *next_count) {
     // Queue space is reserved once per 256-thread block (two atomics per block: same-address atomics from every wave cost
     // ~6 ns each, chip-wide serial).  Inactive threads of the last block take part in the barriers with lit = false, no children.
-    __shared__ int s_lit[4], s_child[4], s_base[2];
+    __shared__ int s_lit[4], s_child[4], s_refl[4], s_base[2];
     const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i0 < n;
     const int i = active ? i0 : n - 1;          // inactive threads recompute the last ray and write nothing
@@ -1252,18 +1252,20 @@ __global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, L
     // ---- block-wide reservation in the shadow queue and in the next level's queue ----
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const unsigned long long m_lit = __ballot(lit), m1 = __ballot(has_refr || has_refl), m2 = __ballot(has_refr && has_refl);
-    if (lane == 0) { s_lit[wave] = __popcll(m_lit); s_child[wave] = __popcll(m1) + __popcll(m2); }
+    const unsigned long long m_lit = __ballot(lit), m1 = __ballot(has_refr), m2 = __ballot(has_refl);
+    if (lane == 0) { s_lit[wave] = __popcll(m_lit); s_child[wave] = __popcll(m1); s_refl[wave] = __popcll(m2); }
     __syncthreads();
     const int block_lit = s_lit[0] + s_lit[1] + s_lit[2] + s_lit[3];
+    const int block_refr = s_child[0] + s_child[1] + s_child[2] + s_child[3];
     if (threadIdx.x == 0) {
-        const int block_child = s_child[0] + s_child[1] + s_child[2] + s_child[3];
+        const int block_child = block_refr + s_refl[0] + s_refl[1] + s_refl[2] + s_refl[3];
         s_base[0] = (block_lit && nl) ? atomicAdd(sb.count, block_lit * nl) : 0;
         s_base[1] = block_child ? atomicAdd(next_count, block_child) : 0;
     }
     __syncthreads();
-    int lit_rank = __popcll(m_lit & below), slot = s_base[1] + __popcll(m1 & below) + __popcll(m2 & below);
-    for (int w = 0; w < wave; ++w) { lit_rank += s_lit[w]; slot += s_child[w]; }
+    // the block's refraction children sit together, then its reflection children (rays of one kind are the coherent ones)
+    int lit_rank = __popcll(m_lit & below), slot_refr = s_base[1] + __popcll(m1 & below), slot_refl = s_base[1] + block_refr + __popcll(m2 & below);
+    for (int w = 0; w < wave; ++w) { lit_rank += s_lit[w]; slot_refr += s_child[w]; slot_refl += s_refl[w]; }
 
     // shadow rays: COMPACT queue; the block's rays towards one light sit together (also the coherent order); the result
     // is written to the ray's slot (hit i, light l) by the trace kernel.
@@ -1282,13 +1284,13 @@ __global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, L
     if (!active) return;
     int ci_refr = -1, ci_refl = -1;
     if (has_refr) {
-        ci_refr = slot++;
+        ci_refr = slot_refr;
         next.ray_o[ci_refr] = make_float4(refr_o.x, refr_o.y, refr_o.z, time);
         next.ray_d[ci_refr] = make_float4(refr_d.x, refr_d.y, refr_d.z, refr_n);
         next.ray_m[ci_refr] = make_int4(meta.x, meta.y, meta.z * 2, refr_c);
     }
     if (has_refl) {
-        ci_refl = slot++;
+        ci_refl = slot_refl;
         next.ray_o[ci_refl] = make_float4(refl_o.x, refl_o.y, refl_o.z, time);
         next.ray_d[ci_refl] = make_float4(refl_d.x, refl_d.y, refl_d.z, refl_n);
         next.ray_m[ci_refl] = make_int4(meta.x, meta.y, meta.z * 2 + 1, refl_c);
