@@ -608,6 +608,9 @@ __device__ __noinline__ void motion_inverse(const DevObject &ob, float time, flo
 }
 
 // What Triangle::Intersect / Sphere::Intersect put into the SurfaceIntersection of the winning primitive.
+// ALL_FIELDS = false (render path): uv is only computed for objects that carry a texture, the only reader of it there; a flat,
+// untextured triangle then needs none of its three vertex records (108 bytes of gathers per hit).
+template <bool ALL_FIELDS>
 __device__ __forceinline__ void finalize_hit(const DevScene &sc, f3 o, f3 d, float time, const Cand &best, HitOut &h) {
     h.t = best.t; h.prim = best.prim; h.ip = best.ip; h.theta = h.phi = 0; h.u = h.v = 0; h.n = mk3(0, 0, 0);
     if (best.prim < 0) { h.shape = -1; h.object = -1; h.t = FLT_MAX; return; }
@@ -623,11 +626,14 @@ __device__ __forceinline__ void finalize_hit(const DevScene &sc, f3 o, f3 d, flo
         const float e = 1 + eps;
         const float w0 = e - best.beta - best.gamma;                           // Triangle.cpp:252-266
         f3 n = ld3(P.nrm);
-        const int *tv = sc.tri_vert + 3 * (size_t)P.shape;
-        const DevVertex &a = sc.verts[tv[0]], &b = sc.verts[tv[1]], &c = sc.verts[tv[2]];
-        h.u = a.uv[0] * w0 + b.uv[0] * best.beta + c.uv[0] * best.gamma;
-        h.v = a.uv[1] * w0 + b.uv[1] * best.beta + c.uv[1] * best.gamma;
-        if (ob.flags & DEV_OBJ_SMOOTH) n = normalize3(ld3(a.n) * w0 + ld3(b.n) * best.beta + ld3(c.n) * best.gamma);
+        const bool smooth = (ob.flags & DEV_OBJ_SMOOTH) != 0;
+        if (ALL_FIELDS || smooth || ob.tex_color >= 0 || ob.tex_normal >= 0) {
+            const int *tv = sc.tri_vert + 3 * (size_t)P.shape;
+            const DevVertex &a = sc.verts[tv[0]], &b = sc.verts[tv[1]], &c = sc.verts[tv[2]];
+            h.u = a.uv[0] * w0 + b.uv[0] * best.beta + c.uv[0] * best.gamma;
+            h.v = a.uv[1] * w0 + b.uv[1] * best.beta + c.uv[1] * best.gamma;
+            if (smooth) n = normalize3(ld3(a.n) * w0 + ld3(b.n) * best.beta + ld3(c.n) * best.gamma);
+        }
         if (!(flags & DEV_OBJ_IDENTITY)) n = normalize3(mat_mul_xyz(inv, n.x, n.y, n.z, 0.0f));   // Triangle.cpp:299-300
         h.n = n;
     } else {
@@ -748,7 +754,7 @@ __global__ __launch_bounds__(256) void k_finalize_batch(DevScene sc, const rt_ra
     Cand best;
     best.t = raw.t; best.prim = raw.shape; best.ip = ld3(raw.ip); best.beta = raw.uv[0]; best.gamma = raw.uv[1];
     HitOut h;
-    finalize_hit(sc, ld3(r.origin), ld3(r.direction), r.time, best, h);
+    finalize_hit<true>(sc, ld3(r.origin), ld3(r.direction), r.time, best, h);
     rt_hit out;
     out.t = h.t; out.shape = h.shape;
     out.ip[0] = h.ip.x; out.ip[1] = h.ip.y; out.ip[2] = h.ip.z;
@@ -1139,7 +1145,7 @@ __global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, L
         Cand best;
         best.t = r0.x; best.prim = __float_as_int(r0.y); best.beta = r0.z; best.gamma = r0.w; best.ip = mk3(r1.x, r1.y, r1.z);
         HitOut h;
-        finalize_hit(sc, o, d, time, best, h);
+        finalize_hit<false>(sc, o, d, time, best, h);
         s.ip = h.ip; s.n = h.n; s.u = h.u; s.v = h.v; s.theta = h.theta; s.phi = h.phi; s.shape = h.shape; s.object = h.object; s.prim = h.prim;
         if (active) {
             lv.hit0[i] = make_float4(h.t, __int_as_float(h.shape), __int_as_float(h.object), __int_as_float(h.prim));
