@@ -421,9 +421,9 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
     hs.params.bg_texture = d->bg_texture;
     hs.params.n_lights = d->n_lights; hs.params.n_materials = d->n_materials; hs.params.n_textures = d->n_textures;
     hs.params.bvh_depth = maxDepth;
-    hs.params.tri_min_lanes = 16;
+    hs.params.tri_min_lanes = RT_TRI_MIN_LANES;
     hs.params.donate = 1;
-    hs.params.refill_min_idle = 24;      // measured: 8 -> 8.8 ms, 24 -> 8.3 ms trace per config-2 frame (the block is ~200 instructions)
+    hs.params.refill_min_idle = RT_REFILL_MIN_IDLE;
     hs.params.has_normal_tex = 0; hs.params.has_rng = 0;
     for (const DevObject &o : hs.objects) if (o.tex_normal >= 0) hs.params.has_normal_tex = 1;
     for (const rt_light &l : hs.lights) if (l.type == RT_LIGHT_AREA) hs.params.has_rng = 1;

@@ -73,6 +73,9 @@ struct DevVertex {            // 32 bytes: what the winner's finalisation reads
 };
 static_assert(sizeof(DevVertex) == 32, "DevVertex must be 32 bytes");
 
+#define RT_TRI_MIN_LANES 16      // run the primitive path of the traversal once this many lanes of a wave wait in a leaf
+#define RT_REFILL_MIN_IDLE 24    // retire + refill (or donate) once this many lanes of a wave are idle (8 -> 8.8 ms, 24 -> 8.1 ms per config-2 frame)
+
 struct DevSceneParams {
     int32_t max_depth;
     float isect_eps, shadow_eps;

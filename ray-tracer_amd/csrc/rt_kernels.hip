@@ -254,8 +254,8 @@ __device__ __noinline__ bool chain_visit(const DevChain *chain, int node, bool l
 // Every iteration a lane that holds a ray does ONE unit of work: a node step (both child boxes) or one primitive test of
 // the leaf it is in.  Node records and primitive records are both 64 bytes, so the same four 16-byte loads fetch either
 // and an iteration costs one memory round trip whatever mix of states the wave is in.  The kernel is VALU-issue bound,
-// so the expensive primitive path only runs when at least TRI_MIN_LANES lanes wait in a leaf (or nothing else is left to
-// do); retiring and refilling is batched the same way (REFILL_MIN_IDLE).
+// so the expensive primitive path only runs when at least tri_min_lanes lanes wait in a leaf (or nothing else is left to
+// do); retiring and refilling is batched the same way (refill_min_idle).
 //
 // Registers: the hit payload that is only needed at the end (ip, beta, gamma of the leaf-local and of the best candidate)
 // lives in LDS next to the traversal stack.
@@ -267,15 +267,13 @@ __device__ __noinline__ bool chain_visit(const DevChain *chain, int node, bool l
 #define CUR_NONE 0x7ffffffd      // no node left to visit (stack empty); the lane may still hold a pending leaf
 #define CUR_WAIT 0x7ffffffc      // lane finished its own traversal and waits for parts it gave away
 #define TRACE_CHUNK 64           // rays a wave reserves per atomic
-#define REFILL_MIN_IDLE 24       // default of DevSceneParams::refill_min_idle: retire + refill once this many lanes are idle
-#define TRI_MIN_LANES 16         // run the primitive path once this many lanes wait in a leaf
-#define LDS_PAYLOAD 15           // dwords per lane: ip.xyz, beta, gamma of the leaf-local candidate, then of the best one, then the
+// (thresholds: DevSceneParams::refill_min_idle / tri_min_lanes, defaults RT_REFILL_MIN_IDLE / RT_TRI_MIN_LANES in rt_device.h)
+#define LDS_PAYLOAD 14           // dwords per lane: ip.xyz, beta, gamma of the leaf-local candidate, then of the best one, then the
                                  // rarely used lane state below
 #define PAY_RAY_IDX 10           // index of the ray in the queue
-#define PAY_PARENT 11            // lane this part of a ray reports to (-1: it owns the ray)
-#define PAY_PENDING 12           // parts given away and not yet merged
-#define PAY_DY 13                // direction y, z (the hot path only needs 1/d and d.x)
-#define PAY_DZ 14
+#define PAY_PENDING 11           // parts given away and not yet merged
+#define PAY_DY 12                // direction y, z (the hot path only needs 1/d and d.x)
+#define PAY_DZ 13
 
 struct TraceDbg { unsigned nodes, boxes, tris, sph, v[10]; };
 
