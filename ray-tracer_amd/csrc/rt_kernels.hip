@@ -21,7 +21,8 @@
 
 #define TRACE_BLOCK 256
 #define LDS_STACK 20
-#define TRACE_BLOCKS_PER_CU 6
+#define TRACE_BLOCKS_PER_CU 6        // sizes the stack-overflow area (upper bound of the grid)
+#define TRACE_RESIDENT_PER_CU 4      // blocks of the traversal kernel a CU holds (128 VGPRs, 35 KB LDS)
 #define NUM_CUS 256
 
 int rt_trace_grid_threads() { return NUM_CUS * TRACE_BLOCKS_PER_CU * TRACE_BLOCK; }
@@ -763,9 +764,11 @@ __global__ __launch_bounds__(256) void k_finalize_batch(DevScene sc, const rt_ra
 
 static int g_trace_block_cap = 0;
 void rt_set_trace_block_cap(int cap) { g_trace_block_cap = cap; }
+// Persistent grid: one block per 256 rays up to the 1024 blocks that are resident at a time (4 per CU); blocks beyond those
+// only start when the queue is already empty.  (Fewer, longer-running blocks for small launches: +27 % time at 200x120.)
 static int trace_blocks(int n) {
     int want = (n + TRACE_BLOCK - 1) / TRACE_BLOCK;
-    int cap = NUM_CUS * TRACE_BLOCKS_PER_CU;
+    int cap = NUM_CUS * TRACE_RESIDENT_PER_CU;
     if (g_trace_block_cap > 0 && g_trace_block_cap < cap) cap = g_trace_block_cap;
     return want < cap ? (want < 1 ? 1 : want) : cap;
 }
