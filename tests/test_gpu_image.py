@@ -127,3 +127,23 @@ def test_exr_half_file_equals_tinyexr_restatement(gpu_ctx, orc, shape):
     assert len(got) == len(want) == gpu_ctx.L.rt_image_encode_bound(nx, ny, abi.RT_IMG_EXR_HALF)
     assert got == want
     assert got[:4] == bytes([0x76, 0x2f, 0x31, 0x01])
+
+
+def test_image_api_argument_errors(rt, gpu_ctx):
+    import ctypes as C
+    f = frame(4, 4, 2)
+    out = np.zeros(4 * 4 * 3, np.float32)
+    o = abi.TonemapOpts(abi.RT_ABI_VERSION + 1, 0.18, 1.0, 1.0, 2.2, 1, 0, 0)
+    assert gpu_ctx.L.rt_tonemap(gpu_ctx.h, f.ctypes.data, 4, 4, C.byref(o), out.ctypes.data, None, None) == abi.RT_ERR_ABI
+    o = abi.TonemapOpts(abi.RT_ABI_VERSION, 0.18, 1.0, 1.0, 2.2, 1, 0, 0)
+    assert gpu_ctx.L.rt_tonemap(gpu_ctx.h, f.ctypes.data, 0, 4, C.byref(o), out.ctypes.data, None, None) == abi.RT_ERR_INVALID
+    assert gpu_ctx.L.rt_tonemap(gpu_ctx.h, None, 4, 4, C.byref(o), out.ctypes.data, None, None) == abi.RT_ERR_INVALID
+    assert gpu_ctx.L.rt_tonemap(gpu_ctx.h, f.ctypes.data, 1 << 15, 1 << 15, C.byref(o), out.ctypes.data, None, None) == abi.RT_ERR_TOO_LARGE
+    n = C.c_size_t(0)
+    buf = np.zeros(1024, np.uint8)
+    assert gpu_ctx.L.rt_image_encode(gpu_ctx.h, f.ctypes.data, 0, 4, 0, abi.RT_IMG_PPM_P3, buf.ctypes.data, 1024, C.byref(n), None) == abi.RT_ERR_INVALID
+    assert gpu_ctx.L.rt_image_encode(gpu_ctx.h, f.ctypes.data, 1 << 15, 1 << 15, 0, abi.RT_IMG_RGB8, buf.ctypes.data, 1024, C.byref(n), None) == abi.RT_ERR_TOO_LARGE
+    assert gpu_ctx.L.rt_image_encode_bound(0, 4, abi.RT_IMG_PPM_P3) == 0 and gpu_ctx.L.rt_image_encode_bound(4, 4, 9) == 0
+    assert b"rt_image_encode" in gpu_ctx.L.rt_last_error(gpu_ctx.h)
+    # the context still works afterwards
+    assert gpu_ctx.encode_image(f, abi.RT_IMG_RGB8).size == 48
