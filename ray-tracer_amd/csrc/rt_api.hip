@@ -158,6 +158,13 @@ struct rt_ctx {
     DevArray<rt_ray> d_rays;
     DevArray<rt_hit> d_hits;
     int overflow_depth = 0;
+    std::vector<hipEvent_t> ev_pool;        // timing events, kept between frames (creating one costs several microseconds)
+    size_t ev_used = 0;
+    hipError_t timing_event(hipEvent_t *out) {
+        if (ev_used == ev_pool.size()) { hipEvent_t e; hipError_t rc = hipEventCreate(&e); if (rc != hipSuccess) return rc; ev_pool.push_back(e); }
+        *out = ev_pool[ev_used++];
+        return hipSuccess;
+    }
     // frame post-processing (rt_image_encode, rt_tonemap)
     DevArray<float> d_img_in, d_tm_lum, d_tm_out, d_tm_params;
     DevArray<uint8_t> d_img8, d_img_text, d_img_tmp;
@@ -171,6 +178,8 @@ static void release_all(rt_ctx *c) {
     for (auto &l : c->lanes) l.release();
     c->lanes.clear();
     if (c->ev_ready) { hipEventDestroy(c->ev_ready); c->ev_ready = nullptr; }
+    for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+    c->ev_pool.clear(); c->ev_used = 0;
     c->d_pixels.release(); c->d_overflow.release();
     c->d_counts.release(); c->d_kind.release(); c->d_counters.release(); c->d_hdr.release(); c->d_pid.release(); c->d_pt.release();
     c->d_rays.release(); c->d_hits.release();
@@ -448,7 +457,8 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
     hipEvent_t ev_first = nullptr, ev_last = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;
     const bool timing = stats && opts->timing;
-    if (timing) { HIP_TRY(c, hipEventCreate(&ev_first)); HIP_TRY(c, hipEventCreate(&ev_last)); HIP_TRY(c, hipEventRecord(ev_first, s)); }
+    c->ev_used = 0;
+    if (timing) { HIP_TRY(c, c->timing_event(&ev_first)); HIP_TRY(c, c->timing_event(&ev_last)); HIP_TRY(c, hipEventRecord(ev_first, s)); }
     uint64_t primary_rays = 0, trace_launches = 0, trace_rays = 0;
     // the batch streams start after the uploads / clears queued on the context stream
     HIP_TRY(c, hipEventRecord(c->ev_ready, s));
@@ -457,7 +467,7 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
     auto timed_trace = [&](hipStream_t st, auto launch) -> int {
         if (timing) {
             hipEvent_t a, b;
-            HIP_TRY(c, hipEventCreate(&a)); HIP_TRY(c, hipEventCreate(&b));
+            HIP_TRY(c, c->timing_event(&a)); HIP_TRY(c, c->timing_event(&b));
             HIP_TRY(c, hipEventRecord(a, st));
             launch();
             HIP_TRY(c, hipEventRecord(b, st));
@@ -630,9 +640,6 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
         }
         stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     }
-    if (ev_first) hipEventDestroy(ev_first);
-    if (ev_last) hipEventDestroy(ev_last);
-    for (auto &pr : trace_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     return RT_OK;
 }
 
