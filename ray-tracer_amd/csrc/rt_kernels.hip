@@ -222,6 +222,33 @@ __device__ __forceinline__ int slab_fast(float bminx, float bminy, float bminz, 
     return diff < 0.0f ? 0 : 1;
 }
 
+// Second look at a LEAF box whose fast test was undecided, still without memory traffic.  The reference's test fails iff some
+// far_b < near_a (or far_b < 0).  A pair from ONE axis can never fail: near and far are the min and max of the same two
+// quotients, in the reference's arithmetic as in this one — which is why every hit on a flat box (near_y == far_y, the
+// config-2 floor) looks undecided to the tn/tf form although nothing about it is close.  So compare across axes only, each
+// pair with the usual 1e-6 margin: a decided failure of any pair is a miss; all pairs decided passes are a hit of this box
+// and, because boxes nest pair by pair, of every ancestor's; anything else stays undecided (a true graze) and takes the walk.
+__device__ __forceinline__ int slab_cross(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, f3 o, f3 r, float amb) {
+    const float ax = (bminx - o.x) * r.x, bx = (bmaxx - o.x) * r.x;
+    const float ay = (bminy - o.y) * r.y, by = (bmaxy - o.y) * r.y;
+    const float az = (bminz - o.z) * r.z, bz = (bmaxz - o.z) * r.z;
+    const float nx = fminf(ax, bx), fx = fmaxf(ax, bx);
+    const float ny = fminf(ay, by), fy = fmaxf(ay, by);
+    const float nz = fminf(az, bz), fz = fmaxf(az, bz);
+    // per axis a: near_a against the smaller far of the other two axes; and 0 against the smallest far
+    const float n[4] = {nx, ny, nz, 0.0f};
+    const float f[4] = {fminf(fy, fz), fminf(fx, fz), fminf(fx, fy), fminf(fminf(fx, fy), fz)};
+    bool miss = false, open = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float diff = f[k] - n[k];
+        const bool decided = fabsf(diff) > amb * (fabsf(f[k]) + fabsf(n[k]));
+        miss = miss || (decided && diff < 0.0f);
+        open = open || !decided;
+    }
+    return miss ? 0 : (open ? 2 : 1);
+}
+
 // Would the reference traversal reach the leaf whose reference node is `node`?  It does iff the exact box test passes
 // for the leaf's box and for every ancestor's (BVHTree.cpp:160-206).  Only called for leaves whose own fast test was
 // undecided (a ray grazing the leaf box within 1e-6 relative — every hit on a flat, axis-aligned leaf box is one — or a ray
@@ -526,7 +553,17 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                 cls[i] = c;
                 key[i] = fminf(fmaxf(tn, 0.0f), FLT_MAX);         // NaN -> 0
             }
-            if (COUNT) { ++dbg.nodes; dbg.boxes += 4; ++ray_steps; if (need_chain) ++dbg.v[9]; if (__any(need_chain)) ++dbg.v[8]; }
+            if (COUNT) { ++dbg.nodes; dbg.boxes += 4; ++ray_steps; }
+            if (need_chain && amb < 1.0f) {
+                need_chain = false;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (cls[i] == 2) {
+                        cls[i] = slab_cross(mnx[i], mny[i], mnz[i], mxx[i], mxy[i], mxz[i], o, r, amb);
+                        need_chain = need_chain || cls[i] == 2;
+                    }
+            }
+            if (COUNT) { if (need_chain) ++dbg.v[9]; if (__any(need_chain)) ++dbg.v[8]; }
             if (need_chain) {
                 const float4 q7 = rec[7];
                 const int cch[4] = {__float_as_int(q7.x), __float_as_int(q7.y), __float_as_int(q7.z), __float_as_int(q7.w)};
