@@ -429,6 +429,7 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
     for (const rt_light &l : hs.lights) if (l.type == RT_LIGHT_AREA) hs.params.has_rng = 1;
     for (const rt_material &m : hs.materials) if (m.roughness > 0) hs.params.has_rng = 1;
     hs.params.has_motion = 0;
+    hs.params.n_objects = (int32_t)hs.objects.size();
     for (const DevObject &o : hs.objects) if (o.flags & DEV_OBJ_MOTION) hs.params.has_motion = 1;
     float scale = 1.0f;
     if (!bn.empty() || device_done)

@@ -95,6 +95,7 @@ struct DevSceneParams {
     int32_t has_normal_tex;   // any object with a normal texture   } select the k_shade_pre instantiation
     int32_t has_rng;          // any area light or glossy material  }
     int32_t has_motion;       // any object with a non-zero motion-blur vector (selects the kernel instantiation)
+    int32_t n_objects;
 };
 #define RT_NO_ROOT 0x7fffffff
 

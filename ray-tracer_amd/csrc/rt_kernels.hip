@@ -96,8 +96,25 @@ __device__ __noinline__ void enter_object_motion(const DevScene &sc, int obj, f3
     out->o = matT_mul_xyz(inv, o.x, o.y, o.z, 1.0f);
     out->d = normalize3(matT_mul_xyz(inv, d.x, d.y, d.z, 0.0f));
 }
+// The traversal keeps the records of the first OBJ_CACHE objects in LDS (OBJ_CACHE_DWORDS each: M, inv, flags): entering an
+// object and taking a hit point back to world space then cost an LDS gather instead of a dependent trip to L2 in the middle of
+// the primitive path (config 2: nearly every primitive-path iteration has a lane that enters an object).
+#define OBJ_CACHE 24
+#define OBJ_CACHE_DWORDS 33
 template <bool MOTION>
-__device__ __forceinline__ void enter_object(const DevScene &sc, int obj, f3 o, f3 d, float time, ObjXf &x) {
+__device__ __forceinline__ void enter_object(const DevScene &sc, const float *objc, int obj, f3 o, f3 d, float time, ObjXf &x) {
+    if (obj < OBJ_CACHE) {
+        const float *c = objc + obj * OBJ_CACHE_DWORDS;
+        const int flags = __float_as_int(c[32]);
+        if (!(MOTION && (flags & DEV_OBJ_HAS_XFORM) && (flags & DEV_OBJ_MOTION))) {
+            x.id = obj;
+            if (!(flags & DEV_OBJ_HAS_XFORM)) { x.flags = flags | DEV_OBJ_IDENTITY; x.o = o; x.d = d; return; }
+            x.flags = flags;
+            x.o = matT_mul_xyz(c + 16, o.x, o.y, o.z, 1.0f);
+            x.d = normalize3(matT_mul_xyz(c + 16, d.x, d.y, d.z, 0.0f));
+            return;
+        }
+    }
     const DevObject &ob = sc.objects[obj];
     const int flags = ob.flags;
     if (MOTION && (flags & DEV_OBJ_HAS_XFORM) && (flags & DEV_OBJ_MOTION)) {
@@ -122,7 +139,11 @@ __device__ __forceinline__ void enter_object(const DevScene &sc, int obj, f3 o, 
 // from the object table (static objects) or rebuilt for the ray's time (moving objects) — only hit candidates of
 // transformed objects come here.
 template <bool MOTION>
-__device__ __forceinline__ f3 object_point_to_world(const DevScene &sc, int obj, float time, f3 p) {
+__device__ __forceinline__ f3 object_point_to_world(const DevScene &sc, const float *objc, int obj, float time, f3 p) {
+    if (obj < OBJ_CACHE) {
+        const float *c = objc + obj * OBJ_CACHE_DWORDS;
+        if (!MOTION || !(__float_as_int(c[32]) & DEV_OBJ_MOTION)) return mat_mul_xyz(c, p.x, p.y, p.z, 1.0f);
+    }
     const DevObject &ob = sc.objects[obj];
     if (!MOTION || !(ob.flags & DEV_OBJ_MOTION)) return mat_mul_xyz(ob.M, p.x, p.y, p.z, 1.0f);
     float M[16];
@@ -137,7 +158,7 @@ __device__ __forceinline__ float det3(float ax, float ay, float az, float bx, fl
 
 // Triangle::Intersect up to the world-space t (Triangle.cpp:115-135, 186-250; Q2, Q6, Q8)
 template <bool MOTION>
-__device__ __forceinline__ bool hit_triangle(const DevScene &sc, const float4 q0, const float4 q1, const float4 q2, const ObjXf &x, float wox, float wdx,
+__device__ __forceinline__ bool hit_triangle(const DevScene &sc, const float *objc, const float4 q0, const float4 q1, const float4 q2, const ObjXf &x, float wox, float wdx,
                                              float time, float eps, Cand &c) {
     const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
     const f3 d = x.d;
@@ -153,7 +174,7 @@ __device__ __forceinline__ bool hit_triangle(const DevScene &sc, const float4 q0
     const float t = det3(e1.x, e2.x, pr.x, e1.y, e2.y, pr.y, e1.z, e2.z, pr.z) * inv;
     if (!(t >= -eps)) return false;
     f3 ip = x.o + d * t;
-    if (!(x.flags & DEV_OBJ_IDENTITY)) ip = object_point_to_world<MOTION>(sc, x.id, time, ip);      // Triangle.cpp:296-298
+    if (!(x.flags & DEV_OBJ_IDENTITY)) ip = object_point_to_world<MOTION>(sc, objc, x.id, time, ip);      // Triangle.cpp:296-298
     c.t = (ip.x - wox) / wdx;                                                  // Ray::operator()(Vector3f), acmath.h:742
     c.ip = ip; c.beta = beta; c.gamma = gamma;
     return true;
@@ -173,10 +194,10 @@ __device__ __forceinline__ bool sphere_t(f3 center, float radius, f3 o, f3 d, fl
     return t > 0;
 }
 template <bool MOTION>
-__device__ __forceinline__ bool hit_sphere(const DevScene &sc, const float4 q0, const ObjXf &x, float wox, float wdx, float time, Cand &c) {
+__device__ __forceinline__ bool hit_sphere(const DevScene &sc, const float *objc, const float4 q0, const ObjXf &x, float wox, float wdx, float time, Cand &c) {
     float t;
     if (!sphere_t(mk3(q0.x, q0.y, q0.z), q0.w, x.o, x.d, t)) return false;
-    f3 ip = object_point_to_world<MOTION>(sc, x.id, time, x.o + x.d * t);             // Sphere.cpp:128 (no identity shortcut, Q9)
+    f3 ip = object_point_to_world<MOTION>(sc, objc, x.id, time, x.o + x.d * t);             // Sphere.cpp:128 (no identity shortcut, Q9)
     c.t = (ip.x - wox) / wdx;
     c.ip = ip; c.beta = 0; c.gamma = 0;
     return true;
@@ -318,7 +339,7 @@ __device__ __forceinline__ int stack_pop(const int *lds_col, const int *ovf_col,
 }
 
 template <bool COUNT, bool MOTION, class IO>
-__device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io, int n, int *fetch_counter, int *lds_col, float *pay,
+__device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io, int n, int *fetch_counter, int *lds_col, float *pay, const float *objc,
                                                  int *ovf_col, int ovf_stride, TraceDbg &dbg, unsigned long long *hist) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -600,15 +621,15 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
             if (do_tri) {
                 // ProcessIntersectionForLeafNode (BVHTree.cpp:177-190): fresh result per leaf, array order, accept t>0 && t < local-0.001
                 const int obj = __float_as_int(q3.x), kind = __float_as_int(q3.z);
-                if (obj != xf.id) enter_object<MOTION>(sc, obj, o, mk3(dirx, pay[PAY_DY * TRACE_BLOCK], pay[PAY_DZ * TRACE_BLOCK]), time, xf);
+                if (obj != xf.id) enter_object<MOTION>(sc, objc, obj, o, mk3(dirx, pay[PAY_DY * TRACE_BLOCK], pay[PAY_DZ * TRACE_BLOCK]), time, xf);
                 Cand c;
                 bool ok;
                 if (kind == DEV_PRIM_TRIANGLE) {
                     if (COUNT) ++dbg.tris;
-                    ok = hit_triangle<MOTION>(sc, q0, q1, q2, xf, o.x, dirx, time, eps, c);
+                    ok = hit_triangle<MOTION>(sc, objc, q0, q1, q2, xf, o.x, dirx, time, eps, c);
                 } else {
                     if (COUNT) ++dbg.sph;
-                    ok = hit_sphere<MOTION>(sc, q0, xf, o.x, dirx, time, c);
+                    ok = hit_sphere<MOTION>(sc, objc, q0, xf, o.x, dirx, time, c);
                 }
                 if (ok && c.t > 0 && c.t < local_t - 0.001f) {
                     local_t = c.t; local_prim = prim_i;
@@ -766,12 +787,22 @@ template <bool COUNT, bool MOTION, class IO>
 __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_trace_generic(DevScene sc, IO io, int n, const int *n_dev, int *fetch_counter, int *ovf, int ovf_stride, DevCounters *counters) {
     __shared__ int s_stack[(LDS_STACK + 1) * TRACE_BLOCK];      // + one scratch row for the branch-free push
     __shared__ float s_pay[LDS_PAYLOAD * TRACE_BLOCK];
+    __shared__ float s_obj[OBJ_CACHE * OBJ_CACHE_DWORDS];
+    {
+        const int nobj = sc.p.n_objects < OBJ_CACHE ? sc.p.n_objects : OBJ_CACHE;
+        for (int i = threadIdx.x; i < nobj * OBJ_CACHE_DWORDS; i += TRACE_BLOCK) {
+            const int ob = i / OBJ_CACHE_DWORDS, k = i - ob * OBJ_CACHE_DWORDS;
+            const DevObject &src = sc.objects[ob];
+            s_obj[i] = k < 16 ? src.M[k] : (k < 32 ? src.inv[k - 16] : __int_as_float(src.flags));
+        }
+        __syncthreads();
+    }
     if (n_dev) n += *n_dev;                       // + the part of the queue whose length was produced on the device
     const int gtid = blockIdx.x * TRACE_BLOCK + threadIdx.x;
     TraceDbg dbg;
     dbg.nodes = dbg.boxes = dbg.tris = dbg.sph = 0;
     for (int k = 0; k < 10; ++k) dbg.v[k] = 0;
-    trace_persistent<COUNT, MOTION, IO>(sc, io, n, fetch_counter, s_stack + threadIdx.x, s_pay + threadIdx.x, ovf + gtid, ovf_stride, dbg,
+    trace_persistent<COUNT, MOTION, IO>(sc, io, n, fetch_counter, s_stack + threadIdx.x, s_pay + threadIdx.x, s_obj, ovf + gtid, ovf_stride, dbg,
                                         (COUNT && counters && counters->want_hist) ? &counters->hist[0] : nullptr);
     flush_counters<COUNT>(counters, dbg.nodes, dbg.boxes, dbg.tris, dbg.sph);
     if (COUNT && counters) {
