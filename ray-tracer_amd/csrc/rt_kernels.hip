@@ -158,9 +158,9 @@ __device__ __forceinline__ float det3(float ax, float ay, float az, float bx, fl
 
 // Triangle::Intersect up to the world-space t (Triangle.cpp:115-135, 186-250; Q2, Q6, Q8)
 template <bool MOTION>
-__device__ __forceinline__ bool hit_triangle(const DevScene &sc, const float *objc, const float4 q0, const float4 q1, const float4 q2, const ObjXf &x, float wox, float wdx,
+__device__ __forceinline__ bool hit_triangle(const DevScene &sc, const float *objc, const float4 q0, const float4 q1, const float q2x, const ObjXf &x, float wox, float wdx,
                                              float time, float eps, Cand &c) {
-    const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
+    const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2x);
     const f3 d = x.d;
     const f3 pr = mk3(p0.x - x.o.x, p0.y - x.o.y, p0.z - x.o.z);
     const float detM = det3(e1.x, e2.x, d.x, e1.y, e2.y, d.y, e1.z, e2.z, d.z);
@@ -540,20 +540,64 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
             else { --sp; cur = stack_pop(lds_col, ovf_col, ovf_stride, sp); }
         }
 
-        // ---------------- one unit of work per lane: a node step or a primitive test ----------------
+        // ---------------- per lane and iteration: a node step AND, when the wave runs its primitive path, one primitive test ----------------
+        // Both records are requested at the top (the primitive record first), the primitive test runs while the node record is
+        // still on its way, then the node step.  A lane in a leaf therefore keeps walking its stack while it works through the
+        // leaf's primitives; the order of visits does not matter for the result (§ exactness).
         const bool in_leaf = has_ray && prim_i < prim_end;
-        const bool can_node = has_ray && cur >= 0 && cur < CUR_WAIT;
-        const int n_leaf = __popcll(__ballot(in_leaf)), n_node = __popcll(__ballot(can_node));
-        const bool run_tri = n_leaf > 0 && (n_leaf >= sc.p.tri_min_lanes || n_leaf >= n_node);      // wave-uniform
+        const bool at_node = has_ray && cur >= 0 && cur < CUR_WAIT;
+        const int n_leaf = __popcll(__ballot(in_leaf)), n_node = __popcll(__ballot(at_node));
+        const bool run_tri = n_leaf > 0 && (n_leaf >= sc.p.tri_min_lanes || n_node == 0);      // wave-uniform
         const bool do_tri = in_leaf && run_tri;
-        const bool at_node = can_node && !do_tri;
-        // every lane loads (idle lanes re-read record 0 of the node array): no merge of loaded and stale registers
-        const float4 *rec = do_tri ? prims4 + 4 * (size_t)prim_i : nodes4 + (at_node ? 8 * (size_t)cur : 0);
-        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+        float4 p0 = make_float4(0, 0, 0, 0), p1 = p0;
+        float p2x = 0;
+        int p_obj = 0, p_kind = 0;
+        if (run_tri) {
+            // every lane loads (the others re-read record 0): no merge of loaded and stale registers
+            const float4 *prec = prims4 + (do_tri ? 4 * (size_t)prim_i : 0);
+            p0 = prec[0]; p1 = prec[1];
+            p2x = reinterpret_cast<const float *>(prec)[8];
+            p_obj = reinterpret_cast<const int *>(prec)[12];
+            p_kind = reinterpret_cast<const int *>(prec)[14];
+        }
+        const float4 *rec = nodes4 + (at_node ? 8 * (size_t)cur : 0);
+        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6];
         if (COUNT) { ++dbg.v[4]; if (at_node) ++dbg.v[5]; if (do_tri) ++dbg.v[7]; if (run_tri) ++dbg.v[6]; }
+        if (run_tri) {
+            if (do_tri) {
+                // ProcessIntersectionForLeafNode (BVHTree.cpp:177-190): fresh result per leaf, array order, accept t>0 && t < local-0.001
+                const int obj = p_obj, kind = p_kind;
+                if (obj != xf.id) enter_object<MOTION>(sc, objc, obj, o, mk3(dirx, pay[PAY_DY * TRACE_BLOCK], pay[PAY_DZ * TRACE_BLOCK]), time, xf);
+                Cand c;
+                bool ok;
+                if (kind == DEV_PRIM_TRIANGLE) {
+                    if (COUNT) ++dbg.tris;
+                    ok = hit_triangle<MOTION>(sc, objc, p0, p1, p2x, xf, o.x, dirx, time, eps, c);
+                } else {
+                    if (COUNT) ++dbg.sph;
+                    ok = hit_sphere<MOTION>(sc, objc, p0, xf, o.x, dirx, time, c);
+                }
+                if (ok && c.t > 0 && c.t < local_t - 0.001f) {
+                    local_t = c.t; local_prim = prim_i;
+                    pay[0 * TRACE_BLOCK] = c.ip.x; pay[1 * TRACE_BLOCK] = c.ip.y; pay[2 * TRACE_BLOCK] = c.ip.z;
+                    pay[3 * TRACE_BLOCK] = c.beta; pay[4 * TRACE_BLOCK] = c.gamma;
+                }
+                if (++prim_i == prim_end) {
+                    // ProcessIntersectionForInternalNode (BVHTree.cpp:192-206) reduced over all leaves: smaller t wins, ties
+                    // go to the leaf that comes later in DFS order (Q4); records are stored in that order, so the leaf's first
+                    // record index against the best record's index decides
+                    if (local_prim >= 0 && (local_t < best_t || (local_t == best_t && leaf_key > best_prim))) {
+                        best_t = local_t; best_prim = local_prim;
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) pay[(5 + k) * TRACE_BLOCK] = pay[k * TRACE_BLOCK];
+                    }
+                    prim_i = prim_end = 0;
+                }
+            }
+        }
+        bound = fminf(bound, best_t);
         if (at_node) {
             // four child boxes (structure of arrays: q0..q2 = min x,y,z of the four children, q3..q5 = max), q6 = references
-            const float4 q4 = rec[4], q5 = rec[5], q6 = rec[6];
             const float mnx[4] = {q0.x, q0.y, q0.z, q0.w}, mny[4] = {q1.x, q1.y, q1.z, q1.w}, mnz[4] = {q2.x, q2.y, q2.z, q2.w};
             const float mxx[4] = {q3.x, q3.y, q3.z, q3.w}, mxy[4] = {q4.x, q4.y, q4.z, q4.w}, mxz[4] = {q5.x, q5.y, q5.z, q5.w};
             int cref[4] = {__float_as_int(q6.x), __float_as_int(q6.y), __float_as_int(q6.z), __float_as_int(q6.w)};
@@ -616,38 +660,6 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                 cur = cref[0];
             } else if (sp == sbase) cur = CUR_NONE;
             else { --sp; cur = stack_pop(lds_col, ovf_col, ovf_stride, sp); }
-        }
-        if (run_tri) {
-            if (do_tri) {
-                // ProcessIntersectionForLeafNode (BVHTree.cpp:177-190): fresh result per leaf, array order, accept t>0 && t < local-0.001
-                const int obj = __float_as_int(q3.x), kind = __float_as_int(q3.z);
-                if (obj != xf.id) enter_object<MOTION>(sc, objc, obj, o, mk3(dirx, pay[PAY_DY * TRACE_BLOCK], pay[PAY_DZ * TRACE_BLOCK]), time, xf);
-                Cand c;
-                bool ok;
-                if (kind == DEV_PRIM_TRIANGLE) {
-                    if (COUNT) ++dbg.tris;
-                    ok = hit_triangle<MOTION>(sc, objc, q0, q1, q2, xf, o.x, dirx, time, eps, c);
-                } else {
-                    if (COUNT) ++dbg.sph;
-                    ok = hit_sphere<MOTION>(sc, objc, q0, xf, o.x, dirx, time, c);
-                }
-                if (ok && c.t > 0 && c.t < local_t - 0.001f) {
-                    local_t = c.t; local_prim = prim_i;
-                    pay[0 * TRACE_BLOCK] = c.ip.x; pay[1 * TRACE_BLOCK] = c.ip.y; pay[2 * TRACE_BLOCK] = c.ip.z;
-                    pay[3 * TRACE_BLOCK] = c.beta; pay[4 * TRACE_BLOCK] = c.gamma;
-                }
-                if (++prim_i == prim_end) {
-                    // ProcessIntersectionForInternalNode (BVHTree.cpp:192-206) reduced over all leaves: smaller t wins, ties
-                    // go to the leaf that comes later in DFS order (Q4); records are stored in that order, so the leaf's first
-                    // record index against the best record's index decides
-                    if (local_prim >= 0 && (local_t < best_t || (local_t == best_t && leaf_key > best_prim))) {
-                        best_t = local_t; best_prim = local_prim;
-#pragma unroll
-                        for (int k = 0; k < 5; ++k) pay[(5 + k) * TRACE_BLOCK] = pay[k * TRACE_BLOCK];
-                    }
-                    prim_i = prim_end = 0;
-                }
-            }
         }
         if (has_ray && cur == CUR_NONE && !(prim_i < prim_end)) cur = CUR_DONE;
     }
