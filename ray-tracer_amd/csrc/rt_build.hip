@@ -417,6 +417,7 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
         store3(hs.params.root_min, bn[0].box.lo); store3(hs.params.root_max, bn[0].box.hi);
     }
     hs.params.max_depth = d->max_depth; hs.params.isect_eps = d->isect_eps; hs.params.shadow_eps = d->shadow_eps;
+    { volatile float one = 1.0f; hs.params.isect_eps_p1 = one + d->isect_eps; }
     for (int k = 0; k < 3; ++k) { hs.params.background[k] = d->background[k]; hs.params.ambient[k] = d->ambient[k]; }
     hs.params.bg_texture = d->bg_texture;
     hs.params.n_lights = d->n_lights; hs.params.n_materials = d->n_materials; hs.params.n_textures = d->n_textures;

@@ -74,7 +74,7 @@ struct DevVertex {            // 32 bytes: what the winner's finalisation reads
 static_assert(sizeof(DevVertex) == 32, "DevVertex must be 32 bytes");
 
 #define RT_TRI_MIN_LANES 16      // run the primitive path of the traversal once this many lanes of a wave wait in a leaf
-#define RT_REFILL_MIN_IDLE 24    // retire + refill (or donate) once this many lanes of a wave are idle (8 -> 8.8 ms, 24 -> 8.1 ms per config-2 frame)
+#define RT_REFILL_MIN_IDLE 16    // retire + refill (or donate) once this many lanes of a wave are idle (sweeps in DESIGN.md §5)
 
 struct DevSceneParams {
     int32_t max_depth;
@@ -96,6 +96,7 @@ struct DevSceneParams {
     int32_t has_rng;          // any area light or glossy material  }
     int32_t has_motion;       // any object with a non-zero motion-blur vector (selects the kernel instantiation)
     int32_t n_objects;
+    float isect_eps_p1;       // 1 + isect_eps in float (Triangle.cpp:219): a kernel argument so that it stays in a scalar register
 };
 #define RT_NO_ROOT 0x7fffffff
 

@@ -138,17 +138,26 @@ __device__ __forceinline__ void enter_object(const DevScene &sc, const float *ob
 // object -> world for a hit point of object `obj` (glm mat*vec4(p,1): (m0*x + m1*y) + (m2*z + m3*1)); the matrix is read
 // from the object table (static objects) or rebuilt for the ray's time (moving objects) — only hit candidates of
 // transformed objects come here.
+// (the path through the object table loads whole columns: with the same scalar loads as the LDS path the compiler merges the two
+// into FLAT loads, whose wait also waits for the node record that is in flight)
+template <bool MOTION>
+__device__ __forceinline__ f3 object_point_to_world_far(const DevObject *objects, int obj, float time, f3 p) {
+    const DevObject &ob = objects[obj];
+    const float4 *m4 = reinterpret_cast<const float4 *>(ob.M);
+    const float4 c0 = m4[0], c1 = m4[1], c2 = m4[2], c3 = m4[3];
+    const float Ms[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
+    if (!MOTION || !(ob.flags & DEV_OBJ_MOTION)) return mat_mul_xyz(Ms, p.x, p.y, p.z, 1.0f);
+    float M[16];
+    mat_translate_mul(ld3(ob.mblur) * time, Ms, M);
+    return mat_mul_xyz(M, p.x, p.y, p.z, 1.0f);
+}
 template <bool MOTION>
 __device__ __forceinline__ f3 object_point_to_world(const DevScene &sc, const float *objc, int obj, float time, f3 p) {
     if (obj < OBJ_CACHE) {
         const float *c = objc + obj * OBJ_CACHE_DWORDS;
         if (!MOTION || !(__float_as_int(c[32]) & DEV_OBJ_MOTION)) return mat_mul_xyz(c, p.x, p.y, p.z, 1.0f);
     }
-    const DevObject &ob = sc.objects[obj];
-    if (!MOTION || !(ob.flags & DEV_OBJ_MOTION)) return mat_mul_xyz(ob.M, p.x, p.y, p.z, 1.0f);
-    float M[16];
-    mat_translate_mul(ld3(ob.mblur) * time, ob.M, M);
-    return mat_mul_xyz(M, p.x, p.y, p.z, 1.0f);
+    return object_point_to_world_far<MOTION>(sc.objects, obj, time, p);
 }
 
 __device__ __forceinline__ float det3(float ax, float ay, float az, float bx, float by, float bz, float cx, float cy, float cz) {
@@ -159,7 +168,7 @@ __device__ __forceinline__ float det3(float ax, float ay, float az, float bx, fl
 // Triangle::Intersect up to the world-space t (Triangle.cpp:115-135, 186-250; Q2, Q6, Q8)
 template <bool MOTION>
 __device__ __forceinline__ bool hit_triangle(const DevScene &sc, const float *objc, const float4 q0, const float4 q1, const float q2x, const ObjXf &x, float wox, float wdx,
-                                             float time, float eps, Cand &c) {
+                                             float time, float eps, float err, Cand &c) {
     const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2x);
     const f3 d = x.d;
     const f3 pr = mk3(p0.x - x.o.x, p0.y - x.o.y, p0.z - x.o.z);
@@ -167,7 +176,6 @@ __device__ __forceinline__ bool hit_triangle(const DevScene &sc, const float *ob
     if (detM == 0.0f) return false;
     const float inv = 1 / detM;
     const float beta = det3(pr.x, e2.x, d.x, pr.y, e2.y, d.y, pr.z, e2.z, d.z) * inv;
-    const float err = 1 + eps;
     if (beta < -eps || beta > err) return false;
     const float gamma = det3(e1.x, pr.x, d.x, e1.y, pr.y, d.y, e1.z, pr.z, d.z) * inv;
     if (gamma < -eps || gamma > err || beta + gamma > err) return false;
@@ -562,6 +570,8 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
         }
         const float4 *rec = nodes4 + (at_node ? 8 * (size_t)cur : 0);
         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6];
+        // keeps the compiler from testing the primitive's kind (and waiting for it) before the node loads above are issued
+        asm volatile("" : "+v"(p_kind), "+v"(p_obj) : : "memory");
         if (COUNT) { ++dbg.v[4]; if (at_node) ++dbg.v[5]; if (do_tri) ++dbg.v[7]; if (run_tri) ++dbg.v[6]; }
         if (run_tri) {
             if (do_tri) {
@@ -572,7 +582,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                 bool ok;
                 if (kind == DEV_PRIM_TRIANGLE) {
                     if (COUNT) ++dbg.tris;
-                    ok = hit_triangle<MOTION>(sc, objc, p0, p1, p2x, xf, o.x, dirx, time, eps, c);
+                    ok = hit_triangle<MOTION>(sc, objc, p0, p1, p2x, xf, o.x, dirx, time, eps, sc.p.isect_eps_p1, c);
                 } else {
                     if (COUNT) ++dbg.sph;
                     ok = hit_sphere<MOTION>(sc, objc, p0, xf, o.x, dirx, time, c);

@@ -1,2 +1,9 @@
-for t in 1536 1024 768 512 384; do echo "small_cap $t"; RT_SMALL_CAP=$t RT_STREAMS=1 RT_SIZES=800x480 timeout -k 10 100 python3 tools/trace_driver.py 5 2>&1 | grep -E "^size" || exit 1; done
-for t in 1536 1024 768; do echo "small_cap $t n<3M"; RT_SMALL_N=3000000 RT_SMALL_CAP=$t RT_STREAMS=1 RT_SIZES=800x480 timeout -k 10 100 python3 tools/trace_driver.py 5 2>&1 | grep -E "^size" || exit 1; done
+#!/bin/bash
+# scratch: sweep of the traversal thresholds (tools/trace_driver.py prints the frame's kernel time)
+for t in 4 8 12 16 24 32; do
+  for r in 16 24 32; do
+    echo -n "tri_min $t refill $r: "
+    RT_TRI_MIN_LANES=$t RT_REFILL_MIN_IDLE=$r RT_SIZES=800x480,1600x960 timeout -k 10 120 python tools/trace_driver.py 5 2>&1 | grep "^size" | sed 's/.*ms_kernels \([0-9.]*\) ms_trace(sum) \([0-9.]*\).*/\1 \2/' | tr '\n' ' '
+    echo
+  done
+done
