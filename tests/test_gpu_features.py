@@ -80,6 +80,15 @@ def test_config5_reduced(rt, orc, gpu_ctx):
     print("config5_reduced", m)
 
 
+def test_more_objects_than_the_traversal_caches(rt, orc, gpu_ctx):
+    """The traversal keeps the first 24 object records in LDS (rt_kernels.hip, OBJ_CACHE); 30 rotated instances + 2 base meshes +
+    the floor = 33 objects, so a third of the hits enter objects / return hit points through the object table in memory."""
+    soup = synth.instanced_scene(30, 1500, 160, 90, 2, perlin_table=rt.renderer.perlin_tables(1)[0])
+    assert len(soup.objects) > 24
+    m = run(rt, orc, gpu_ctx, soup)
+    print("33 objects", m)
+
+
 def test_config4_with_dielectric(rt, orc, gpu_ctx, scene_path):
     """BASELINE config 4 as SURVEY 8d words it: cornellbox_boxes_dynamic (motion-blurred instance, mirror + Phong) PLUS the
     dielectric sphere of config 1, so that refraction queues diverge under motion blur.  Reduced spp / resolution."""

@@ -42,8 +42,9 @@ def grazing_rays(soup, n, seed):
 
 @pytest.mark.parametrize("name", ["cornellbox", "cornellbox_boxes_dynamic", "cube_point", "metal_glass_plates", "scienceTree"])
 def test_grazing_and_axis_parallel_rays(rt, orc, gpu_ctx, scene_path, name):
-    """Undecided leaf boxes (flat boxes of axis-aligned quads, rays through box corners, zero direction components) take the
-    exact chain walk; the result must be the oracle's for every ray, including which rays hit nothing."""
+    """Undecided leaf boxes: flat boxes of axis-aligned quads hit in their interior are decided by the cross-axis test
+    (slab_cross), rays through box corners and edges (cross-axis grazes) and zero direction components take the exact chain
+    walk; the result must be the oracle's for every ray, including which rays hit nothing."""
     soup = rt.SceneSoup.load(scene_path(name))
     rays = grazing_rays(soup, 30000, 11)
     g = rt.Mi355Accelerator(soup, context=gpu_ctx).Intersect(rays)
