@@ -314,6 +314,29 @@ typedef struct rt_tonemap_opts {
 int rt_tonemap(rt_ctx *ctx, const float *hdr_rgb, int nx, int ny, const rt_tonemap_opts *opts, float *out_rgb,
                float *out_params, double *ms_kernels);
 
+/* Body of a binary_little_endian PLY file as the caller's header parse describes it. */
+typedef struct rt_ply_layout {
+    uint32_t abi_version;
+    int32_t pos_type;         /* type of the x, y, z properties: 0 = float (32 bit), 1 = double                          */
+    int64_t n_vertices;
+    int32_t vertex_stride;    /* bytes per vertex record (all its properties are scalars)                                */
+    int32_t pos_offset[3];    /* byte offsets of x, y, z inside a vertex record                                          */
+    int64_t n_faces;
+    int32_t face_pre_bytes;   /* bytes of scalar properties before the vertex_indices list in a face record              */
+    int32_t count_size;       /* bytes of the list's count field: 1, 2 or 4                                              */
+    int32_t index_size;       /* bytes per index: 1, 2 or 4                                                              */
+    int32_t face_post_bytes;  /* bytes of scalar properties after the list                                               */
+} rt_ply_layout;              /* 56 bytes */
+
+/* Replaces the PLY branch of the scene parser (src/SceneParser.cpp:983-1023: happly's getVertexPositions() rounded to
+ * Vector3f, getFaceIndices() with a face of three indices kept as a triangle, a face of four split into (0,1,2), (2,3,0),
+ * any other face dropped) for a binary body; the text header stays with the caller.  vertex_bytes / face_bytes: HOST
+ * pointers to the first vertex / face record (face_bytes_size = bytes available from there).  out_pos: HOST [n_vertices*3]
+ * float.  out_tris: HOST [up to 2*n_faces*3] int32 vertex indices, *out_n_tris their number.  Indices are not range-checked
+ * here (rt_scene_upload does that).  No CPU fallback: RT_ERR_NO_DEVICE without a GPU. */
+int rt_ply_decode(rt_ctx *ctx, const void *vertex_bytes, const void *face_bytes, size_t face_bytes_size, const rt_ply_layout *layout,
+                  float *out_pos, int32_t *out_tris, int64_t *out_n_tris, double *ms_kernels);
+
 /* Host-only view of the BVH that rt_scene_upload would build (reference topology, BVHTree.cpp:39-153), so that tests
  * can compare it with an independent build without a GPU.  Leaves are listed in left-to-right DFS order.
  *   leaf_start_end      [2*n_leaves]  range of each leaf in the reference's re-ordered primitive array
@@ -334,7 +357,7 @@ int rt_host_bvh_leaves(const rt_host_bvh *bvh, int64_t *leaf_start_end, int32_t 
 void rt_host_bvh_free(rt_host_bvh *bvh);
 
 /* sizeof() of the ABI structs, in header order (0 rt_material, 1 rt_light, 2 rt_texture, 3 rt_object, 4 rt_scene_desc,
- * 5 rt_camera_desc, 6 rt_render_opts, 7 rt_stats, 8 rt_ray, 9 rt_hit, 10 rt_bvh_info, 11 rt_tonemap_opts); -1 for anything else. */
+ * 5 rt_camera_desc, 6 rt_render_opts, 7 rt_stats, 8 rt_ray, 9 rt_hit, 10 rt_bvh_info, 11 rt_tonemap_opts, 12 rt_ply_layout); -1 for anything else. */
 int rt_abi_sizeof(int which);
 
 uint32_t rt_abi_version(void);

@@ -74,6 +74,16 @@ public:
         Check(rt_tonemap(h_, rgb, nx, ny, &o, out.data(), nullptr, nullptr));
         return out;
     }
+    // body of a binary PLY (layout from the caller's header parse) -> positions [nv*3] and triangle indices [nt*3]
+    void DecodePly(const void *vertex_bytes, const void *face_bytes, size_t face_bytes_size, rt_ply_layout layout, std::vector<float> &pos,
+                   std::vector<int32_t> &tris) {
+        layout.abi_version = RT_ABI_VERSION;
+        pos.resize((size_t)layout.n_vertices * 3);
+        tris.resize((size_t)layout.n_faces * 6);
+        int64_t n = 0;
+        Check(rt_ply_decode(h_, vertex_bytes, face_bytes, face_bytes_size, &layout, pos.data(), tris.data(), &n, nullptr));
+        tris.resize((size_t)n * 3);
+    }
     rt_ctx *handle() const { return h_; }
 
 private:

@@ -104,6 +104,12 @@ class TonemapOpts(C.Structure):
                 ("gamma", C.c_float), ("input_8bit", C.c_int32), ("in_on_device", C.c_int32), ("out_on_device", C.c_int32)]
 
 
+class PlyLayout(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("pos_type", C.c_int32), ("n_vertices", C.c_int64), ("vertex_stride", C.c_int32),
+                ("pos_offset", C.c_int32 * 3), ("n_faces", C.c_int64), ("face_pre_bytes", C.c_int32), ("count_size", C.c_int32),
+                ("index_size", C.c_int32), ("face_post_bytes", C.c_int32)]
+
+
 class BvhInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_int64), ("n_leaves", C.c_int64), ("max_depth", C.c_int32), ("n_wide_nodes", C.c_int32),
                 ("n_leaf_prims", C.c_int64)]

@@ -169,6 +169,11 @@ struct rt_ctx {
     DevArray<float> d_img_in, d_tm_lum, d_tm_out, d_tm_params;
     DevArray<uint8_t> d_img8, d_img_text, d_img_tmp;
     DevArray<unsigned long long> d_img_len, d_img_off;
+    // PLY decoding
+    DevArray<uint8_t> d_ply_in, d_ply_tmp;
+    DevArray<float> d_ply_pos;
+    DevArray<int> d_ply_tri, d_ply_cnt;
+    DevArray<long long> d_ply_off;
     DevArray<double> d_tm_partial;
 };
 
@@ -185,6 +190,7 @@ static void release_all(rt_ctx *c) {
     c->d_rays.release(); c->d_hits.release();
     c->d_img_in.release(); c->d_tm_lum.release(); c->d_tm_out.release(); c->d_tm_params.release();
     c->d_img8.release(); c->d_img_text.release(); c->d_img_tmp.release(); c->d_img_len.release(); c->d_img_off.release(); c->d_tm_partial.release();
+    c->d_ply_in.release(); c->d_ply_tmp.release(); c->d_ply_pos.release(); c->d_ply_tri.release(); c->d_ply_cnt.release(); c->d_ply_off.release();
 }
 
 extern "C" {
@@ -872,6 +878,86 @@ int rt_tonemap(rt_ctx *c, const float *hdr_rgb, int nx, int ny, const rt_tonemap
     return RT_OK;
 }
 
+// ---- PLY body -> positions + triangles (rt_ply.hip) -----------------------------------------------------
+int rt_ply_decode(rt_ctx *c, const void *vertex_bytes, const void *face_bytes, size_t face_bytes_size, const rt_ply_layout *L, float *out_pos, int32_t *out_tris,
+                  int64_t *out_n_tris, double *ms_kernels) {
+    if (!c) return RT_ERR_INVALID;
+    if (!L || L->abi_version != RT_ABI_VERSION) { c->error = "rt_ply_decode: abi_version mismatch"; return RT_ERR_ABI; }
+    const int64_t nv = L->n_vertices, nf = L->n_faces;
+    auto size_ok = [](int v) { return v == 1 || v == 2 || v == 4; };
+    if (nv < 0 || nf < 0 || !out_n_tris || (nv > 0 && (!vertex_bytes || !out_pos)) || (nf > 0 && (!face_bytes || !out_tris)) || (L->pos_type != 0 && L->pos_type != 1) ||
+        !size_ok(L->count_size) || !size_ok(L->index_size) || L->face_pre_bytes < 0 || L->face_post_bytes < 0) { c->error = "rt_ply_decode: bad argument"; return RT_ERR_INVALID; }
+    const int csz = L->pos_type ? 8 : 4;
+    for (int k = 0; k < 3; ++k)
+        if (L->pos_offset[k] < 0 || L->pos_offset[k] + csz > L->vertex_stride) { c->error = "rt_ply_decode: position offset outside the vertex record"; return RT_ERR_INVALID; }
+    if (nv > 0x7fffffffLL || nf > 0x3fffffffLL) { c->error = "rt_ply_decode: more than 2^31 vertices or 2^30 faces"; return RT_ERR_TOO_LARGE; }
+    const uint8_t *fb = static_cast<const uint8_t *>(face_bytes);
+    auto count_at = [&](size_t pos) { unsigned v = fb[pos]; if (L->count_size >= 2) v |= (unsigned)fb[pos + 1] << 8; if (L->count_size == 4) v |= (unsigned)fb[pos + 2] << 16 | (unsigned)fb[pos + 3] << 24; return v; };
+    const size_t fixed = (size_t)L->face_pre_bytes + L->count_size + L->face_post_bytes;
+    unsigned k0 = 0;
+    if (nf > 0) {
+        if (face_bytes_size < fixed) { c->error = "rt_ply_decode: face data truncated"; return RT_ERR_INVALID; }
+        k0 = count_at(L->face_pre_bytes);
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const size_t vbytes = (size_t)nv * L->vertex_stride;
+    HIP_TRY(c, c->d_ply_in.ensure(vbytes + face_bytes_size + 16));
+    HIP_TRY(c, c->d_ply_pos.ensure((size_t)nv * 3 + 1));
+    HIP_TRY(c, c->d_ply_tri.ensure((size_t)nf * 6 + 1));
+    HIP_TRY(c, c->d_ply_cnt.ensure(2 * ((size_t)nf + 1) + 1));
+    uint8_t *d_vb = c->d_ply_in.p, *d_fb = c->d_ply_in.p + vbytes;
+    if (vbytes) HIP_TRY(c, hipMemcpyAsync(d_vb, vertex_bytes, vbytes, hipMemcpyHostToDevice, s));
+    if (nf > 0) HIP_TRY(c, hipMemcpyAsync(d_fb, face_bytes, face_bytes_size, hipMemcpyHostToDevice, s));
+    int *d_flag = c->d_ply_cnt.p + 2 * ((size_t)nf + 1);
+    HIP_TRY(c, hipMemsetAsync(d_flag, 0, sizeof(int), s));
+    EventPair ev;
+    HIP_TRY(c, ev.start(ms_kernels != nullptr, s));
+    HIP_TRY(c, rt_ply_vertices(s, d_vb, nv, L->vertex_stride, L->pos_offset, L->pos_type, c->d_ply_pos.p));
+    // one face size for the whole file?  (the records are then at i * record size; the kernel checks every count)
+    const size_t rec0 = fixed + (size_t)k0 * L->index_size;
+    bool uniform = nf > 0 && rec0 <= face_bytes_size / (size_t)nf;
+    int64_t n_tris = 0;
+    if (uniform) {
+        HIP_TRY(c, rt_ply_faces_uniform(s, d_fb, nf, L->face_pre_bytes, L->count_size, L->index_size, L->face_post_bytes, k0, c->d_ply_tri.p, d_flag));
+        int flag = 0;
+        HIP_TRY(c, hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (flag) uniform = false;
+        else n_tris = k0 == 3 ? nf : (k0 == 4 ? 2 * nf : 0);
+    }
+    if (!uniform && nf > 0) {
+        // mixed face sizes: the offsets are a dependent chain over the counts (host, one pass), the rest stays on the device
+        std::vector<long long> offs((size_t)nf);
+        size_t pos = 0;
+        for (int64_t i = 0; i < nf; ++i) {
+            if (pos + fixed > face_bytes_size) { c->error = "rt_ply_decode: face data truncated"; return RT_ERR_INVALID; }
+            offs[(size_t)i] = (long long)pos;
+            pos += fixed + (size_t)count_at(pos + L->face_pre_bytes) * L->index_size;
+        }
+        if (pos > face_bytes_size) { c->error = "rt_ply_decode: face data truncated"; return RT_ERR_INVALID; }
+        size_t scan_bytes = 0;
+        HIP_TRY(c, rt_ply_scan_bytes(nf, &scan_bytes));
+        HIP_TRY(c, c->d_ply_tmp.ensure(scan_bytes + 16));
+        HIP_TRY(c, c->d_ply_off.ensure((size_t)nf));
+        HIP_TRY(c, hipMemcpyAsync(c->d_ply_off.p, offs.data(), (size_t)nf * sizeof(long long), hipMemcpyHostToDevice, s));
+        int *d_ntri = c->d_ply_cnt.p, *d_toff = c->d_ply_cnt.p + (nf + 1);
+        HIP_TRY(c, rt_ply_faces_mixed_count(s, d_fb, c->d_ply_off.p, nf, L->face_pre_bytes, L->count_size, d_ntri, d_toff, c->d_ply_tmp.p, scan_bytes));
+        HIP_TRY(c, rt_ply_faces_mixed_write(s, d_fb, c->d_ply_off.p, d_toff, nf, L->face_pre_bytes, L->count_size, L->index_size, c->d_ply_tri.p));
+        int total = 0;
+        HIP_TRY(c, hipMemcpyAsync(&total, d_toff + nf, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));      // `offs` and `total` are host memory of this call
+        n_tris = total;
+    }
+    HIP_TRY(c, ev.stop(s));
+    if (nv > 0) HIP_TRY(c, hipMemcpyAsync(out_pos, c->d_ply_pos.p, (size_t)nv * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (n_tris > 0) HIP_TRY(c, hipMemcpyAsync(out_tris, c->d_ply_tri.p, (size_t)n_tris * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    *out_n_tris = n_tris;
+    if (ms_kernels) *ms_kernels = ev.ms();
+    return RT_OK;
+}
+
 // ---- host-only BVH view for tests (no GPU needed) ------------------------------------------------------
 struct rt_host_bvh { HostScene hs; std::string error; };
 
@@ -923,6 +1009,7 @@ int rt_abi_sizeof(int which) {
     case 9: return (int)sizeof(rt_hit);
     case 10: return (int)sizeof(rt_bvh_info);
     case 11: return (int)sizeof(rt_tonemap_opts);
+    case 12: return (int)sizeof(rt_ply_layout);
     default: return -1;
     }
 }

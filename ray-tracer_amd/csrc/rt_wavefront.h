@@ -98,6 +98,14 @@ hipError_t rt_img_p3_measure(hipStream_t s, const uint8_t *rgb, int64_t npx, int
                              void *scan_tmp, size_t scan_bytes);
 hipError_t rt_img_p3_write(hipStream_t s, const uint8_t *rgb, int64_t npx, int nx, const unsigned long long *block_off, uint8_t *out_body);
 hipError_t rt_img_exr_rows(hipStream_t s, const float *rgb, int nx, int ny, uint8_t *body);   // body: ny * (8 + 6 nx) bytes, 2-byte aligned
+
+// ---- PLY body decoding (rt_ply.hip) ----
+hipError_t rt_ply_vertices(hipStream_t s, const uint8_t *vb, int64_t nv, int stride, const int off[3], int type, float *out);
+hipError_t rt_ply_faces_uniform(hipStream_t s, const uint8_t *fb, int64_t nf, int pre, int csize, int isize, int post, unsigned k0, int *out, int *mismatch);
+hipError_t rt_ply_scan_bytes(int64_t nf, size_t *bytes);
+hipError_t rt_ply_faces_mixed_count(hipStream_t s, const uint8_t *fb, const long long *offs, int64_t nf, int pre, int csize, int *ntri, int *tri_off, void *scan_tmp,
+                                    size_t scan_bytes);
+hipError_t rt_ply_faces_mixed_write(hipStream_t s, const uint8_t *fb, const long long *offs, const int *tri_off, int64_t nf, int pre, int csize, int isize, int *out);
 #define RT_TM_WORK_WORDS (4 + 2048)   // select state + histogram of rt_img_tonemap
 hipError_t rt_img_tonemap(hipStream_t s, const void *src, int from8, int64_t npx, float key, float burn_percent, float saturation,
                           float *lum, double *partial, unsigned *partial_max, unsigned *work, float *params, float *out);

@@ -59,6 +59,7 @@ def library():
     L.rt_image_encode_bound.restype = C.c_size_t
     L.rt_image_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, P(C.c_size_t), P(C.c_double)]
     L.rt_tonemap.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, P(abi.TonemapOpts), C.c_void_p, C.c_void_p, P(C.c_double)]
+    L.rt_ply_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, P(abi.PlyLayout), C.c_void_p, C.c_void_p, P(C.c_int64), P(C.c_double)]
     if L.rt_abi_version() != abi.RT_ABI_VERSION:
         raise RtError(abi.RT_ERR_ABI, "librt_mi355.so ABI %d != python mirror %d" % (L.rt_abi_version(), abi.RT_ABI_VERSION))
     _lib = L
@@ -204,6 +205,21 @@ class Context:
         self._check(self.L.rt_image_encode(self.h, hdr if on_device else hdr.ctypes.data, nx, ny, int(on_device), fmt, out.ctypes.data, cap,
                                            C.byref(n), C.byref(ms) if timing else None))
         return (out[:n.value], ms.value) if timing else out[:n.value]
+
+    def decode_ply(self, vertex_bytes, face_bytes, layout, timing=False):
+        """Body of a binary_little_endian PLY -> (positions float32 [nv, 3], triangles int32 [nt, 3]) on the device
+        (rt_ply_decode: SceneParser.cpp:983-1023).  vertex_bytes / face_bytes: bytes-like, starting at the first vertex /
+        face record; layout: abi.PlyLayout filled from the header (scene.ply_layout)."""
+        vb = np.frombuffer(vertex_bytes, np.uint8)
+        fb = np.frombuffer(face_bytes, np.uint8)
+        pos = np.empty((int(layout.n_vertices), 3), np.float32)
+        tris = np.empty((2 * int(layout.n_faces), 3), np.int32)
+        n = C.c_int64(0)
+        ms = C.c_double(0)
+        self._check(self.L.rt_ply_decode(self.h, vb.ctypes.data if len(vb) else None, fb.ctypes.data if len(fb) else None, len(fb), C.byref(layout),
+                                         pos.ctypes.data, tris.ctypes.data, C.byref(n), C.byref(ms) if timing else None))
+        tris = tris[:n.value]
+        return (pos, tris, ms.value) if timing else (pos, tris)
 
     def tonemap(self, hdr, key, burn_percent, saturation, gamma=2.2, input_8bit=True, nx=None, ny=None, timing=False):
         """Tonemapper::Tonemap (DefaultTonemapStrategy) on the device.  Returns (rgb float32 [ny, nx, 3], (average luminance,

@@ -426,28 +426,91 @@ def _floats(text):
     return [float(x) for x in text.split()]
 
 
-def _read_ply(path):
-    """Minimal PLY reader (ascii / binary_little_endian; vertex x,y,z + face vertex_indices lists) standing in for
-    happly (src/SceneParser.cpp:983-985).  Quads become (0,1,2),(2,3,0) as in SceneParser.cpp:995-1011."""
+_PLY_TYPES = {"char": "i1", "uchar": "u1", "short": "i2", "ushort": "u2", "int": "i4", "uint": "u4", "float": "f4", "double": "f8",
+              "int8": "i1", "uint8": "u1", "int16": "i2", "uint16": "u2", "int32": "i4", "uint32": "u4", "float32": "f4", "float64": "f8"}
+
+
+def _ply_header(f):
+    """Reads the text header of an open PLY file; returns (format, [element dicts in file order])."""
+    header = []
+    while True:
+        raw = f.readline()
+        if not raw:
+            raise ValueError("PLY header without end_header")
+        line = raw.decode("ascii", "replace").strip()
+        header.append(line)
+        if line == "end_header":
+            break
+    fmt = [h.split()[1] for h in header if h.startswith("format")][0]
+    elements, cur = [], None
+    for h in header:
+        p = h.split()
+        if p and p[0] == "element":
+            cur = {"name": p[1], "count": int(p[2]), "props": []}
+            elements.append(cur)
+        elif p and p[0] == "property" and cur is not None:
+            cur["props"].append(p[1:])
+    return fmt, elements
+
+
+def ply_layout(elements):
+    """abi.PlyLayout of a binary PLY body for rt_ply_decode, or None when the file needs the general reader (elements other
+    than vertex + face, list properties in the vertex element, more than one list in the face element, exotic types)."""
+    if [e["name"] for e in elements] != ["vertex", "face"]:
+        return None
+    ve, fe = elements
+    L = abi.PlyLayout()
+    L.abi_version = abi.RT_ABI_VERSION
+    off, where = 0, {}
+    for p in ve["props"]:
+        if p[0] == "list" or p[0] not in _PLY_TYPES:
+            return None
+        where[p[-1]] = (off, _PLY_TYPES[p[0]])
+        off += np.dtype(_PLY_TYPES[p[0]]).itemsize
+    if not all(k in where for k in "xyz") or len({where[k][1] for k in "xyz"}) != 1 or where["x"][1] not in ("f4", "f8"):
+        return None
+    L.pos_type = 1 if where["x"][1] == "f8" else 0
+    L.n_vertices, L.vertex_stride = ve["count"], off
+    for k, name in enumerate("xyz"):
+        L.pos_offset[k] = where[name][0]
+    pre = post = 0
+    lst = None
+    for p in fe["props"]:
+        if p[0] == "list":
+            if lst is not None or p[-1] not in ("vertex_indices", "vertex_index"):
+                return None
+            lst = p
+        elif p[0] not in _PLY_TYPES:
+            return None
+        elif lst is None:
+            pre += np.dtype(_PLY_TYPES[p[0]]).itemsize
+        else:
+            post += np.dtype(_PLY_TYPES[p[0]]).itemsize
+    if lst is None or lst[1] not in _PLY_TYPES or lst[2] not in _PLY_TYPES or _PLY_TYPES[lst[1]][0] == "f" or _PLY_TYPES[lst[2]][0] == "f":
+        return None
+    L.count_size, L.index_size = np.dtype(_PLY_TYPES[lst[1]]).itemsize, np.dtype(_PLY_TYPES[lst[2]]).itemsize
+    if L.count_size == 8 or L.index_size == 8:
+        return None
+    L.n_faces, L.face_pre_bytes, L.face_post_bytes = fe["count"], pre, post
+    return L
+
+
+def _read_ply(path, decoder=None):
+    """PLY reader (ascii / binary_little_endian; vertex x,y,z + face vertex_indices lists) standing in for happly
+    (src/SceneParser.cpp:983-985).  Quads become (0,1,2),(2,3,0) as in SceneParser.cpp:995-1011, faces of any other size are
+    dropped.  `decoder` (Context.decode_ply) decodes a binary body on the GPU; without it numpy does."""
     with open(path, "rb") as f:
-        header = []
-        while True:
-            line = f.readline().decode("ascii", "replace").strip()
-            header.append(line)
-            if line == "end_header":
-                break
-        fmt = [h.split()[1] for h in header if h.startswith("format")][0]
-        elements, cur = [], None
-        for h in header:
-            p = h.split()
-            if p and p[0] == "element":
-                cur = {"name": p[1], "count": int(p[2]), "props": []}
-                elements.append(cur)
-            elif p and p[0] == "property" and cur is not None:
-                cur["props"].append(p[1:])
-        tmap = {"char": "i1", "uchar": "u1", "short": "i2", "ushort": "u2", "int": "i4", "uint": "u4", "float": "f4", "double": "f8",
-                "int8": "i1", "uint8": "u1", "int16": "i2", "uint16": "u2", "int32": "i4", "uint32": "u4", "float32": "f4", "float64": "f8"}
+        fmt, elements = _ply_header(f)
+        tmap = _PLY_TYPES
+        if fmt == "binary_little_endian" and decoder is not None:
+            L = ply_layout(elements)
+            if L is not None:
+                body = f.read()
+                vbytes = int(L.n_vertices) * int(L.vertex_stride)
+                pos, tris = decoder(memoryview(body)[:vbytes], memoryview(body)[vbytes:], L)
+                return pos, tris.astype(np.int64)
         verts, faces = None, []
+        quads_tris = None
         if fmt == "ascii":
             tokens = f.read().split()
             pos = 0
@@ -457,7 +520,7 @@ def _read_ply(path):
                     names = [p[-1] for p in el["props"]]
                     arr = np.array(tokens[pos:pos + n * el["count"]], dtype=np.float64).reshape(el["count"], n)
                     pos += n * el["count"]
-                    verts = arr[:, [names.index(b"x".decode()), names.index("y"), names.index("z")]]
+                    verts = arr[:, [names.index("x"), names.index("y"), names.index("z")]]
                 elif el["name"] == "face":
                     for _ in range(el["count"]):
                         k = int(tokens[pos])
@@ -479,22 +542,44 @@ def _read_ply(path):
                     arr = np.frombuffer(f.read(dt.itemsize * el["count"]), dt)
                     verts = np.stack([arr["x"], arr["y"], arr["z"]], 1).astype(np.float64)
                 elif el["name"] == "face":
-                    p = el["props"][0]
+                    lists = [p for p in el["props"] if p[0] == "list"]
+                    p = lists[0]
+                    k_list = el["props"].index(p)
+                    pre = sum(np.dtype(tmap[q[0]]).itemsize for q in el["props"][:k_list])
+                    post = sum(np.dtype(tmap[q[0]]).itemsize for q in el["props"][k_list + 1:]) if len(lists) == 1 else None
                     cdt, idt = np.dtype("<" + tmap[p[1]]), np.dtype("<" + tmap[p[2]])
                     buf = f.read()
+                    # fast path: all faces have the same arity (and no second list)
+                    if post is not None and el["count"] > 0 and len(buf) >= pre + cdt.itemsize:
+                        k0 = int(np.frombuffer(buf, cdt, 1, pre)[0])
+                        rdt = np.dtype([("a", "u1", pre), ("k", cdt), ("i", idt, k0), ("b", "u1", post)])
+                        if len(buf) >= rdt.itemsize * el["count"]:
+                            arr = np.frombuffer(buf, rdt, el["count"], 0)
+                            if np.all(arr["k"] == k0):
+                                idx = arr["i"].astype(np.int64).reshape(el["count"], k0)
+                                if k0 == 3:
+                                    quads_tris = idx
+                                elif k0 == 4:
+                                    quads_tris = np.stack([idx[:, [0, 1, 2]], idx[:, [2, 3, 0]]], 1).reshape(-1, 3)
+                                else:
+                                    quads_tris = np.zeros((0, 3), np.int64)
+                                continue
+                    assert post is not None, "face element with several list properties"
                     pos = 0
-                    # fast path: all faces have the same arity
-                    k0 = int(np.frombuffer(buf, cdt, 1, 0)[0])
-                    rec = cdt.itemsize + k0 * idt.itemsize
-                    if len(el["props"]) == 1 and len(buf) >= rec * el["count"]:
-                        rdt = np.dtype([("k", cdt), ("i", idt, k0)])
-                        arr = np.frombuffer(buf, rdt, el["count"], 0)
-                        if np.all(arr["k"] == k0):
-                            faces = arr["i"].astype(np.int64).tolist()
-                            continue
                     for _ in range(el["count"]):
+                        pos += pre
                         k = int(np.frombuffer(buf, cdt, 1, pos)[0]); pos += cdt.itemsize
-                        faces.append(np.frombuffer(buf, idt, k, pos).astype(np.int64).tolist()); pos += k * idt.itemsize
+                        faces.append(np.frombuffer(buf, idt, k, pos).astype(np.int64).tolist()); pos += k * idt.itemsize + post
+                else:
+                    for _ in range(el["count"]):
+                        for p in el["props"]:
+                            if p[0] == "list":
+                                k = int(np.frombuffer(f.read(np.dtype(tmap[p[1]]).itemsize), "<" + tmap[p[1]])[0])
+                                f.read(k * np.dtype(tmap[p[2]]).itemsize)
+                            else:
+                                f.read(np.dtype(tmap[p[0]]).itemsize)
+        if quads_tris is not None:
+            return verts.astype(F32), quads_tris
         tris = []
         for v in faces:
             if len(v) == 4:
@@ -516,7 +601,7 @@ def _dedup_mesh(indices):
     return uniq, remap[flat].reshape(-1, 3)
 
 
-def load_xml(path, scene_dir=None, texture_loader=None, perlin_tables=None):
+def load_xml(path, scene_dir=None, texture_loader=None, perlin_tables=None, ply_decoder=None):
     """Parses a reference scene file.  `scene_dir` is the directory PLY paths are relative to ("scenes/" in the
     reference, SceneParser.cpp:977).  `texture_loader(path)` must return an HxWx3 uint8 (or float32 for .exr) array;
     default uses Pillow.  `perlin_tables(n)` returns n shuffled 16-entry tables (rt_perlin_tables of the library)."""
@@ -709,7 +794,7 @@ def load_xml(path, scene_dir=None, texture_loader=None, perlin_tables=None):
         mb = tuple(_floats(txt(e, "MotionBlur"))[:3]) if txt(e, "MotionBlur") else (0.0, 0.0, 0.0)
         smooth = e.get("shadingMode") == "smooth"
         if fe.get("plyFile"):
-            pos, faces = _read_ply(os.path.join(scene_dir, fe.get("plyFile")))
+            pos, faces = _read_ply(os.path.join(scene_dir, fe.get("plyFile")), ply_decoder)
             used, faces = _dedup_mesh(faces)
             mpos, muv = pos[used], np.zeros((len(used), 2), F32)
         else:

@@ -1,0 +1,50 @@
+"""The loader's PLY reader (host, numpy) against hand-built files: the reference's own ASCII PLYs are read through happly and
+turned into triangles by SceneParser.cpp:983-1023 (quad -> (0,1,2), (2,3,0); other sizes dropped).  The same files are the
+inputs of the GPU decoder's parity test (tests/test_gpu_ply.py)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import ply_util
+
+scene = importlib.import_module("ray-tracer_amd.scene")
+abi = importlib.import_module("ray-tracer_amd").abi
+
+
+@pytest.mark.parametrize("name", sorted(ply_util.CASES))
+def test_binary_reader(tmp_path, name):
+    kw = dict(ply_util.CASES[name])
+    pos, faces = ply_util.random_mesh(5, 50, 200, kw.pop("sizes"))
+    path = os.path.join(tmp_path, name + ".ply")
+    ply_util.write_binary_ply(path, pos, faces, **kw)
+    got_pos, got_tris = scene._read_ply(path)
+    want = pos.astype(np.float32) if kw.get("pos_type", "f4") == "f8" else pos.astype(np.float32)
+    assert np.array_equal(got_pos, want)
+    assert np.array_equal(got_tris, ply_util.expected_triangles(faces))
+
+
+def test_ascii_reader(tmp_path):
+    path = os.path.join(tmp_path, "a.ply")
+    with open(path, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\nelement face 3\n"
+                "property list uchar int vertex_index\nend_header\n0 0 0\n0 0 1\n1 0 1\n1 0 0\n4 0 1 2 3\n3 0 1 2\n5 0 1 2 3 0\n")
+    pos, tris = scene._read_ply(path)
+    assert pos.shape == (4, 3) and pos.dtype == np.float32
+    assert tris.tolist() == [[0, 1, 2], [2, 3, 0], [0, 1, 2]]
+
+
+def test_layout_from_header(tmp_path):
+    kw = dict(ply_util.CASES["face_scalars_around_list"])
+    pos, faces = ply_util.random_mesh(1, 10, 7, kw.pop("sizes"))
+    path = os.path.join(tmp_path, "l.ply")
+    ply_util.write_binary_ply(path, pos, faces, vertex_extra=(("nx", "f4"),), **kw)
+    with open(path, "rb") as f:
+        fmt, elements = scene._ply_header(f)
+    L = scene.ply_layout(elements)
+    assert fmt == "binary_little_endian"
+    assert (L.abi_version, L.pos_type, L.n_vertices, L.vertex_stride, list(L.pos_offset)) == (abi.RT_ABI_VERSION, 0, 10, 16, [0, 4, 8])
+    assert (L.n_faces, L.face_pre_bytes, L.count_size, L.index_size, L.face_post_bytes) == (7, 1, 1, 4, 6)
+    # an element the decoder does not know sends the file to the general reader
+    assert scene.ply_layout(elements + [{"name": "edge", "count": 0, "props": []}]) is None
