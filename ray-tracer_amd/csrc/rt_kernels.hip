@@ -22,7 +22,7 @@
 #define TRACE_BLOCK 256
 #define LDS_STACK 20
 #define TRACE_BLOCKS_PER_CU 6        // sizes the stack-overflow area (upper bound of the grid)
-#define TRACE_RESIDENT_PER_CU 4      // blocks of the traversal kernel a CU holds (128 VGPRs, 35 KB LDS)
+#define TRACE_RESIDENT_PER_CU 4      // blocks of the traversal kernel a CU holds (128 VGPRs, 39 KB LDS each of the 160 KB)
 #define NUM_CUS 256
 
 int rt_trace_grid_threads() { return NUM_CUS * TRACE_BLOCKS_PER_CU * TRACE_BLOCK; }
@@ -304,15 +304,16 @@ __device__ __noinline__ bool chain_visit(const DevChain *chain, int node, bool l
 // ----------------------------------------------------------------------------------------------------
 // Persistent wave64 traversal with per-lane ray refill.
 //
-// Rays differ wildly in traversal length (config 2: mean 49 nodes + 7 primitive tests, tail > 400).  A wave is a persistent
-// worker: it owns a chunk of the ray queue (one atomic per TRACE_CHUNK rays) and whenever enough lanes are idle they retire
-// their results and start new rays while the other lanes continue.
+// Rays differ wildly in traversal length (config 2: mean 25 wide-node steps + 7 primitive tests, tail > 400).  A wave is a
+// persistent worker: it owns a chunk of the ray queue (one atomic per TRACE_CHUNK rays) and whenever enough lanes are idle
+// they retire their results and start new rays while the other lanes continue.
 //
-// Every iteration a lane that holds a ray does ONE unit of work: a node step (both child boxes) or one primitive test of
-// the leaf it is in.  Node records and primitive records are both 64 bytes, so the same four 16-byte loads fetch either
-// and an iteration costs one memory round trip whatever mix of states the wave is in.  The kernel is VALU-issue bound,
-// so the expensive primitive path only runs when at least tri_min_lanes lanes wait in a leaf (or nothing else is left to
-// do); retiring and refilling is batched the same way (refill_min_idle).
+// Every iteration a lane that holds a ray does a node step (four child boxes) and, when the wave runs its primitive path,
+// one primitive test of its pending leaf.  Both records are requested at the top of the iteration, the primitive record
+// first, so an iteration costs one memory round trip and the primitive test runs while the node record is in flight —
+// provided nothing in between waits for ALL outstanding loads (spill reloads, FLAT loads, a hoisted use of the primitive
+// record: see DESIGN.md section 4).  The expensive primitive path only runs when at least tri_min_lanes lanes hold a pending
+// leaf (or no lane has a node left); retiring and refilling is batched the same way (refill_min_idle).
 //
 // Registers: the hit payload that is only needed at the end (ip, beta, gamma of the leaf-local and of the best candidate)
 // lives in LDS next to the traversal stack.
