@@ -561,16 +561,18 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
         float4 p0 = make_float4(0, 0, 0, 0), p1 = p0;
         float p2x = 0;
         int p_obj = 0, p_kind = 0;
-        if (run_tri) {
-            // every lane loads (the others re-read record 0): no merge of loaded and stale registers
-            const float4 *prec = prims4 + (do_tri ? 4 * (size_t)prim_i : 0);
+        // only the lanes that will use a record request it: an idle lane's load would cost the vector cache as many tag
+        // look-ups as a working lane's
+        if (do_tri) {
+            const float4 *prec = prims4 + 4 * (size_t)prim_i;
             p0 = prec[0]; p1 = prec[1];
             p2x = reinterpret_cast<const float *>(prec)[8];
             p_obj = reinterpret_cast<const int *>(prec)[12];
             p_kind = reinterpret_cast<const int *>(prec)[14];
         }
-        const float4 *rec = nodes4 + (at_node ? 8 * (size_t)cur : 0);
-        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6];
+        float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0, q6 = q0;
+        const float4 *rec = nodes4 + 8 * (size_t)(at_node ? cur : 0);
+        if (at_node) { q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3]; q4 = rec[4]; q5 = rec[5]; q6 = rec[6]; }
         // keeps the compiler from testing the primitive's kind (and waiting for it) before the node loads above are issued
         asm volatile("" : "+v"(p_kind), "+v"(p_obj) : : "memory");
         if (COUNT) { ++dbg.v[4]; if (at_node) ++dbg.v[5]; if (do_tri) ++dbg.v[7]; if (run_tri) ++dbg.v[6]; }
