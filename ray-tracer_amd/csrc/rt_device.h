@@ -43,13 +43,14 @@ struct DevLeaf {
 enum { DEV_PRIM_TRIANGLE = 0, DEV_PRIM_SPHERE = 1 };
 
 struct alignas(64) DevPrim {
+    // the first 48 bytes are what the traversal reads per primitive test (three 16-byte loads)
     float p0[3];              // triangle: v0 position            | sphere: centre
     float e1[3];              // triangle: p0p1 = p0 - p1         | sphere: radius, 0, 0
     float e2[3];              // triangle: p0p2 = p0 - p2
-    float nrm[3];             // triangle: object-space unit normal (Triangle.cpp:37)
     int32_t object;           // DevObject index (transform, material, textures, container identity)
-    int32_t shape;            // rt_hit.shape id: triangle index, or sphere index | RT_PRIM_SPHERE
     int32_t kind;             // DEV_PRIM_*
+    int32_t shape;            // rt_hit.shape id: triangle index, or sphere index | RT_PRIM_SPHERE
+    float nrm[3];             // triangle: object-space unit normal (Triangle.cpp:37)
     int32_t _pad;
 };
 static_assert(sizeof(DevPrim) == 64, "DevPrim must be 64 bytes");

@@ -361,7 +361,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
     float amb = 1e-6f;
     int sp = 0, cur = CUR_DONE, prim_i = 0, prim_end = 0;
     int *payi = reinterpret_cast<int *>(pay);
-    int best_prim = -1, local_prim = -1, leaf_key = 0;
+    int best_prim = -1, local_prim = -1;
     float best_t = FLT_MAX, local_t = FLT_MAX;
     f3 o = mk3(0, 0, 0), r = mk3(0, 0, 1), marg = mk3(0, 0, 0);
     float dirx = 0;                  // d.x (Q2: every hit parameter divides by it); d.y, d.z live in LDS
@@ -543,7 +543,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
             const unsigned u = (unsigned)~cur;
             int start = (int)(u & ((1u << DEV_LEAF_START_BITS) - 1)), count = (int)(u >> DEV_LEAF_START_BITS);
             if (count == 0) { const DevLeaf lf = sc.leaves[start]; start = lf.start; count = lf.count; }
-            prim_i = start; prim_end = start + count; leaf_key = start;
+            prim_i = start; prim_end = start + count;
             local_t = FLT_MAX; local_prim = -1;
             if (sp == sbase) cur = CUR_NONE;
             else { --sp; cur = stack_pop(lds_col, ovf_col, ovf_stride, sp); }
@@ -566,9 +566,8 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
         if (do_tri) {
             const float4 *prec = prims4 + 4 * (size_t)prim_i;
             p0 = prec[0]; p1 = prec[1];
-            p2x = reinterpret_cast<const float *>(prec)[8];
-            p_obj = reinterpret_cast<const int *>(prec)[12];
-            p_kind = reinterpret_cast<const int *>(prec)[14];
+            const float4 p2 = prec[2];                       // e2.z, object, kind, shape (DevPrim, rt_device.h)
+            p2x = p2.x; p_obj = __float_as_int(p2.y); p_kind = __float_as_int(p2.z);
         }
         float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0, q6 = q0;
         const float4 *rec = nodes4 + 8 * (size_t)(at_node ? cur : 0);
@@ -597,9 +596,9 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                 }
                 if (++prim_i == prim_end) {
                     // ProcessIntersectionForInternalNode (BVHTree.cpp:192-206) reduced over all leaves: smaller t wins, ties
-                    // go to the leaf that comes later in DFS order (Q4); records are stored in that order, so the leaf's first
-                    // record index against the best record's index decides
-                    if (local_prim >= 0 && (local_t < best_t || (local_t == best_t && leaf_key > best_prim))) {
+                    // go to the leaf that comes later in DFS order (Q4); records are stored in that order and a leaf's records
+                    // are contiguous, so any record index of this leaf against the best record's index (another leaf's) decides
+                    if (local_prim >= 0 && (local_t < best_t || (local_t == best_t && local_prim > best_prim))) {
                         best_t = local_t; best_prim = local_prim;
 #pragma unroll
                         for (int k = 0; k < 5; ++k) pay[(5 + k) * TRACE_BLOCK] = pay[k * TRACE_BLOCK];
