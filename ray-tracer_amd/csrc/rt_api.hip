@@ -419,6 +419,7 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
     if (const char *tml = getenv("RT_TRI_MIN_LANES")) c->dev.p.tri_min_lanes = atoi(tml);
     if (const char *dn = getenv("RT_DONATE")) c->dev.p.donate = atoi(dn);
     if (const char *ri = getenv("RT_REFILL_MIN_IDLE")) c->dev.p.refill_min_idle = atoi(ri);
+    if (const char *di = getenv("RT_DONATE_MIN_IDLE")) c->dev.p.donate_min_idle = atoi(di);
     if (const char *ps = getenv("RT_PRUNE_SCALE")) { c->dev.p.prune_err = c->host.params.prune_err * (float)atof(ps); c->dev.p.prune_rel = c->host.params.prune_rel * (float)atof(ps); }
     // streams
     int n_streams = opts->num_streams > 0 ? std::min<int>(opts->num_streams, RT_MAX_STREAMS) : RT_DEFAULT_STREAMS;

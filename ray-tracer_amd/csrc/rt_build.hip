@@ -425,6 +425,7 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
     hs.params.tri_min_lanes = RT_TRI_MIN_LANES;
     hs.params.donate = 1;
     hs.params.refill_min_idle = RT_REFILL_MIN_IDLE;
+    hs.params.donate_min_idle = RT_DONATE_MIN_IDLE;
     hs.params.has_normal_tex = 0; hs.params.has_rng = 0;
     for (const DevObject &o : hs.objects) if (o.tex_normal >= 0) hs.params.has_normal_tex = 1;
     for (const rt_light &l : hs.lights) if (l.type == RT_LIGHT_AREA) hs.params.has_rng = 1;

@@ -75,6 +75,7 @@ struct DevVertex {            // 32 bytes: what the winner's finalisation reads
 static_assert(sizeof(DevVertex) == 32, "DevVertex must be 32 bytes");
 
 #define RT_TRI_MIN_LANES 16      // run the primitive path of the traversal once this many lanes of a wave wait in a leaf
+#define RT_DONATE_MIN_IDLE 32    // once the queue is empty: split the rays in flight (donation) when this many lanes of a wave are idle (28-36 measured best)
 #define RT_REFILL_MIN_IDLE 16    // retire + refill (or donate) once this many lanes of a wave are idle (sweeps in DESIGN.md §5)
 
 struct DevSceneParams {
@@ -92,6 +93,7 @@ struct DevSceneParams {
     int32_t stack_bound;      // most entries a traversal of the 4-wide tree can have on its stack
     int32_t tri_min_lanes;    // run the primitive path of the traversal once this many lanes of a wave wait in a leaf
     int32_t refill_min_idle;  // retire + refill (or donate) once this many lanes of a wave are idle
+    int32_t donate_min_idle;  // the same threshold once the queue is empty (donation rounds)
     int32_t donate;           // 1: idle lanes of a wave take over stack entries of its long rays once the queue is empty
     int32_t has_normal_tex;   // any object with a normal texture   } select the k_shade_pre instantiation
     int32_t has_rng;          // any area light or glossy material  }

@@ -392,7 +392,8 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
             bool fin = has_ray && cur == CUR_DONE;
             const unsigned long long idle0 = __ballot(!has_ray || fin);
             unsigned long long parts_done = any_parts ? __ballot(fin && plane != lane) : 0ull;
-            if (__popcll(idle0) >= sc.p.refill_min_idle || parts_done || !__any(working)) {
+            const int min_idle = (exhausted && chunk_next >= chunk_end) ? sc.p.donate_min_idle : sc.p.refill_min_idle;
+            if (__popcll(idle0) >= min_idle || parts_done || !__any(working)) {
                 // 1. merge finished parts into the lanes they report to
                 while (parts_done) {
                     const int s = __ffsll((long long)parts_done) - 1;
@@ -484,7 +485,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                         }
                     }
                     chunk_next += nidle < avail ? nidle : avail;
-                } else if (nidle >= sc.p.refill_min_idle && sc.p.donate) {
+                } else if (nidle >= min_idle && sc.p.donate) {
                     // 3b. nothing left in the queue: split the rays still in flight
                     const bool can_give = has_ray && cur != CUR_DONE && sp > sbase;
                     const unsigned long long givers = __ballot(can_give);
