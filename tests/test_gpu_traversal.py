@@ -63,7 +63,8 @@ def _render(ctx, **kw):
 
 def test_donation_streams_and_batches_do_not_change_a_bit(rt, gpu_ctx, scene_path):
     """Work donation splits a ray's traversal over lanes and merges by the (t, record order) rule; several streams and small
-    batches change which rays share a wave.  None of it may change a single bit of the frame or of the primary hit ids."""
+    batches change which rays share a wave, the scheduling thresholds change which lanes work when.  None of it may change a
+    single bit of the frame or of the primary hit ids."""
     soup = rt.SceneSoup.load(scene_path("cornellbox_recursive"))
     gpu_ctx.upload(soup)
     old = os.environ.get("RT_DONATE")
@@ -74,6 +75,13 @@ def test_donation_streams_and_batches_do_not_change_a_bit(rt, gpu_ctx, scene_pat
         variants = [_render(gpu_ctx, nx=200, ny=200),
                     _render(gpu_ctx, nx=200, ny=200, num_streams=3),
                     _render(gpu_ctx, nx=200, ny=200, num_streams=2, max_batch_samples=4096)]
+        for knob, value in (("RT_DONATE_MIN_IDLE", "1"), ("RT_DONATE_MIN_IDLE", "63"), ("RT_REFILL_MIN_IDLE", "1"), ("RT_TRI_MIN_LANES", "1"),
+                            ("RT_TRI_MIN_LANES", "64")):
+            os.environ[knob] = value                      # scheduling thresholds of the traversal: which lanes work when
+            try:
+                variants.append(_render(gpu_ctx, nx=200, ny=200))
+            finally:
+                os.environ.pop(knob, None)
     finally:
         if old is None:
             os.environ.pop("RT_DONATE", None)
