@@ -490,28 +490,34 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                     const bool can_give = has_ray && cur != CUR_DONE && sp > sbase;
                     const unsigned long long givers = __ballot(can_give);
                     const int ngive = __popcll(givers);
-                    const int np = nidle < ngive ? nidle : ngive;
-                    if (np > 0) {
-                        int entry = 0;
-                        if (can_give && __popcll(givers & lt_mask) < np) {
-                            entry = stack_pop(lds_col, ovf_col, ovf_stride, sbase);
-                            ++sbase;
-                            payi[PAY_PENDING * TRACE_BLOCK] += 1;
-                        }
+                    if (ngive > 0) {
+                        // idle lane number i takes entry i / ngive (counted from the bottom) of giver number i % ngive: a wave with
+                        // few long rays left fills its idle lanes in one round
                         const int irank = __popcll(idle & lt_mask);
-                        const bool take = !has_ray && irank < np;
                         int src = lane;
-                        if (take) {                                   // the irank-th giver
+                        if (!has_ray) {
                             unsigned long long m = givers;
-                            for (int q = 0; q < irank; ++q) m &= m - 1;
+                            for (int q = irank % ngive; q > 0; --q) m &= m - 1;
                             src = __ffsll((long long)m) - 1;
+                        }
+                        const int g_sbase = __shfl(sbase, src), g_sp = __shfl(sp, src);
+                        const int slot = g_sbase + irank / ngive;
+                        const bool take = !has_ray && slot < g_sp;
+                        int entry = 0;
+                        if (take) entry = stack_pop(lds_col + (src - lane), ovf_col + (src - lane), ovf_stride, slot);
+                        if (can_give) {
+                            const int grank = __popcll(givers & lt_mask);
+                            const int want = (nidle - grank + ngive - 1) / ngive;       // idle lanes assigned to this giver
+                            const int given = want < sp - sbase ? want : sp - sbase;
+                            sbase += given;
+                            payi[PAY_PENDING * TRACE_BLOCK] += given;
                         }
                         const float ox = __shfl(o.x, src), oy = __shfl(o.y, src), oz = __shfl(o.z, src);
                         const float dx = __shfl(dirx, src);
                         const float rx = __shfl(r.x, src), ry = __shfl(r.y, src), rz = __shfl(r.z, src);
                         const float mx = __shfl(marg.x, src), my = __shfl(marg.y, src), mz = __shfl(marg.z, src);
                         const float tm = __shfl(time, src), am = __shfl(amb, src), bd = __shfl(bound, src);
-                        const int en = __shfl(entry, src);
+                        const int en = entry;
                         if (take) {
                             o = mk3(ox, oy, oz); dirx = dx; r = mk3(rx, ry, rz); marg = mk3(mx, my, mz);
                             time = tm; amb = am;
