@@ -159,6 +159,12 @@ def main():
                 survey = {"bytes_per_ray": round(cc["bytes_per_ray"], 1), "nodes_per_ray": round(cc["nodes"] / cc["rays"], 2),
                           "tris_per_ray": round(cc["tris"] / cc["rays"], 2), "achieved": round(sbytes / (avg_launch_ms * 1e-3) / 1e9, 2),
                           "frac": round(sbytes / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                # SURVEY 8(d)'s flop count of the same canonical traversal (24 per node visit, 140 per triangle, 60 per sphere test)
+                # against the FP32 vector peak it names (157 TFLOP/s): the path is nowhere near a compute roofline
+                sflops = 24.0 * cc["nodes"] + 140.0 * cc["tris"] + 60.0 * cc["spheres"]
+                survey["flops_per_ray"] = round(sflops / cc["rays"], 1)
+                survey["tflops"] = round(sflops / (trace_ms * 1e-3) / 1e12, 3)
+                survey["frac_fp32_valu_157"] = round(sflops / (trace_ms * 1e-3) / 1e12 / 157.0, 5)
         except Exception:
             survey = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -191,7 +197,7 @@ def main():
            "config": {"workload": "BASELINE config 2: other_dragon.xml camera/lights/materials, depth 6, 1 spp, stand-in %d-triangle mesh "
                                   "(dragon_remeshed.ply is a missing blob) + mirror floor" % args.tris,
                       "resolution": [nx, ny], "spp": 1, "rays_per_frame": int(total_rays), "tiles": "%dx%d interleaved over %d GPU(s)" % (TILE, TILE, world),
-                      "bvh_nodes": int(bvh.n_nodes), "bvh_depth": int(bvh.max_depth), "scene_upload_s": round(upload_s, 2)},
+                      "bvh_nodes": int(bvh.n_nodes), "bvh_depth": int(bvh.max_depth), "scene_upload_s": round(upload_s, 2), "kernels_ms_per_frame": round(sum(s.ms_kernels for s in st_steps) / args.steps, 4)},
            "roofline": roofline, "cpu_baseline": cpu}
     print(json.dumps(out))
     if world > 1:
