@@ -535,10 +535,11 @@ def _read_ply(path, decoder=None):
                             else:
                                 pos += 1
         else:
-            assert fmt == "binary_little_endian", fmt
+            assert fmt in ("binary_little_endian", "binary_big_endian"), fmt
+            E = "<" if fmt == "binary_little_endian" else ">"           # happly reads both byte orders
             for el in elements:
                 if el["name"] == "vertex":
-                    dt = np.dtype([(p[-1], "<" + tmap[p[0]]) for p in el["props"]])
+                    dt = np.dtype([(p[-1], E + tmap[p[0]]) for p in el["props"]])
                     arr = np.frombuffer(f.read(dt.itemsize * el["count"]), dt)
                     verts = np.stack([arr["x"], arr["y"], arr["z"]], 1).astype(np.float64)
                 elif el["name"] == "face":
@@ -547,7 +548,7 @@ def _read_ply(path, decoder=None):
                     k_list = el["props"].index(p)
                     pre = sum(np.dtype(tmap[q[0]]).itemsize for q in el["props"][:k_list])
                     post = sum(np.dtype(tmap[q[0]]).itemsize for q in el["props"][k_list + 1:]) if len(lists) == 1 else None
-                    cdt, idt = np.dtype("<" + tmap[p[1]]), np.dtype("<" + tmap[p[2]])
+                    cdt, idt = np.dtype(E + tmap[p[1]]), np.dtype(E + tmap[p[2]])
                     buf = f.read()
                     # fast path: all faces have the same arity (and no second list)
                     if post is not None and el["count"] > 0 and len(buf) >= pre + cdt.itemsize:
@@ -574,7 +575,7 @@ def _read_ply(path, decoder=None):
                     for _ in range(el["count"]):
                         for p in el["props"]:
                             if p[0] == "list":
-                                k = int(np.frombuffer(f.read(np.dtype(tmap[p[1]]).itemsize), "<" + tmap[p[1]])[0])
+                                k = int(np.frombuffer(f.read(np.dtype(tmap[p[1]]).itemsize), E + tmap[p[1]])[0])
                                 f.read(k * np.dtype(tmap[p[2]]).itemsize)
                             else:
                                 f.read(np.dtype(tmap[p[0]]).itemsize)

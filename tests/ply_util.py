@@ -5,20 +5,21 @@ _T = {"i1": "char", "u1": "uchar", "i2": "short", "u2": "ushort", "i4": "int", "
 
 
 def write_binary_ply(path, pos, faces, pos_type="f4", count_type="u1", index_type="i4", vertex_extra=(), face_pre=(), face_post=(), xyz_first=True,
-                     list_name="vertex_indices"):
+                     list_name="vertex_indices", big_endian=False):
     """pos [nv,3]; faces: list of index lists (any sizes).  vertex_extra / face_pre / face_post: sequences of (name, numpy type code)
     scalar properties filled with a deterministic pattern.  xyz_first=False puts the extra vertex properties before x, y, z."""
+    E = ">" if big_endian else "<"
     pos = np.asarray(pos, np.float64)
     vprops = [("x", pos_type), ("y", pos_type), ("z", pos_type)]
     vprops = (vprops + list(vertex_extra)) if xyz_first else (list(vertex_extra) + vprops)
-    head = ["ply", "format binary_little_endian 1.0", "comment written by tests/ply_util.py", "element vertex %d" % len(pos)]
+    head = ["ply", "format binary_%s_endian 1.0" % ("big" if big_endian else "little"), "comment written by tests/ply_util.py", "element vertex %d" % len(pos)]
     head += ["property %s %s" % (_T[t], n) for n, t in vprops]
     head += ["element face %d" % len(faces)]
     head += ["property %s %s" % (_T[t], n) for n, t in face_pre]
     head += ["property list %s %s %s" % (_T[count_type], _T[index_type], list_name)]
     head += ["property %s %s" % (_T[t], n) for n, t in face_post]
     head += ["end_header"]
-    vdt = np.dtype([(n, "<" + t) for n, t in vprops])
+    vdt = np.dtype([(n, E + t) for n, t in vprops])
     v = np.zeros(len(pos), vdt)
     for k, n in enumerate("xyz"):
         v[n] = pos[:, k]
@@ -27,11 +28,11 @@ def write_binary_ply(path, pos, faces, pos_type="f4", count_type="u1", index_typ
     body = [v.tobytes()]
     for i, f in enumerate(faces):
         for j, (n, t) in enumerate(face_pre):
-            body.append(np.array([(i * 7 + j) % 97], "<" + t).tobytes())
-        body.append(np.array([len(f)], "<" + count_type).tobytes())
-        body.append(np.asarray(f, "<" + index_type).tobytes())
+            body.append(np.array([(i * 7 + j) % 97], E + t).tobytes())
+        body.append(np.array([len(f)], E + count_type).tobytes())
+        body.append(np.asarray(f, E + index_type).tobytes())
         for j, (n, t) in enumerate(face_post):
-            body.append(np.array([(i * 5 + j) % 89], "<" + t).tobytes())
+            body.append(np.array([(i * 5 + j) % 89], E + t).tobytes())
     with open(path, "wb") as fh:
         fh.write(("\n".join(head) + "\n").encode("ascii"))
         fh.write(b"".join(body))

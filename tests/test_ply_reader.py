@@ -25,6 +25,17 @@ def test_binary_reader(tmp_path, name):
     assert np.array_equal(got_tris, ply_util.expected_triangles(faces))
 
 
+def test_big_endian_reader(tmp_path):
+    """happly reads binary_big_endian too; the host reader does, the device decoder is little-endian only (the loader then keeps the host path)."""
+    pos, faces = ply_util.random_mesh(6, 40, 120, (3, 4))
+    path = os.path.join(tmp_path, "be.ply")
+    ply_util.write_binary_ply(path, pos, faces, big_endian=True, index_type="u2", face_post=(("q", "f4"),))
+    called = []
+    got_pos, got_tris = scene._read_ply(path, lambda *a: called.append(1))
+    assert not called
+    assert np.array_equal(got_pos, pos.astype(np.float32)) and np.array_equal(got_tris, ply_util.expected_triangles(faces))
+
+
 def test_ascii_reader(tmp_path):
     path = os.path.join(tmp_path, "a.ply")
     with open(path, "w") as f:
