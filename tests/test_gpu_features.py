@@ -46,6 +46,21 @@ def test_perlin_scenes(rt, orc, gpu_ctx, scene_path, name):
     print(name, run(rt, orc, gpu_ctx, soup, nx=200, ny=200))
 
 
+# The reference's own textured scenes (image textures from its textures/ directory, converted by tools/convert_scenes.py):
+# replace_kd / blend_kd / bump_normal / replace_normal decals on meshes and spheres, nearest and bilinear lookup, a background
+# texture, composed transformations, a 50k-triangle ASCII PLY mesh.
+@pytest.mark.parametrize("name,spp,res", [
+    ("cube_wall", 1, 200), ("cube_wall_normal", 1, 200), ("cube_waves", 1, 200), ("cube_cushion", 1, 200),
+    ("sphere_nearest_bilinear", 1, 200), ("sphere_nobump_bump", 1, 200), ("sphere_normal", 4, 160), ("ellipsoids_texture", 1, 200),
+    ("galactica_static", 1, 320), ("simple_transform", 4, 160), ("cube_point_hdr", 1, 200), ("tap_0200", 4, 200),
+])
+def test_reference_textured_scenes(rt, orc, gpu_ctx, scene_path, name, spp, res):
+    soup = rt.SceneSoup.load(scene_path(name))
+    c = soup.cameras[0]
+    ny = max(8, int(res * c["ny"] / c["nx"]))
+    print(name, run(rt, orc, gpu_ctx, soup, num_samples=spp, nx=res, ny=ny))
+
+
 @pytest.mark.parametrize("tri,sph,tk,sk,bg", [
     (abi.RT_DECAL_REPLACE_KD, abi.RT_DECAL_BLEND_KD, "image", "image", False),
     (abi.RT_DECAL_BUMP_NORMAL, abi.RT_DECAL_BUMP_NORMAL, "image", "image", True),

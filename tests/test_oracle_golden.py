@@ -63,3 +63,27 @@ def test_oracle_frame_digests(frames, name):
     assert hashlib.sha256(pid.tobytes()).hexdigest() == e["sha256_prim_id"]      # hit ids do not depend on libm
     assert [int(x) for x in st.rays] == e["rays"]
     assert abs(float(hdr.astype(np.float64).sum()) - e["hdr_sum"]) <= 1e-6 * abs(e["hdr_sum"])
+
+
+# ---- the reference's image-textured scenes against its published renders -------------------------------------------------
+TEXTURED = json.load(open(os.path.join(GOLD, "oracle_textured_frames.json")))
+
+
+@pytest.mark.parametrize("name", sorted(TEXTURED))
+def test_oracle_vs_published_textured_png(rt, frames, name):
+    """Image textures (replace_kd, blend_kd, bump and normal maps, nearest / bilinear look-up, textures/ of the reference) through
+    loader + oracle against the author's render of the same scene, by the means of 16x16-pixel blocks: per pixel the published
+    files differ from the current sources by sub-texel amounts (older revision), and the two Perlin ellipsoids of ellipsoids_texture
+    by the reference's start-up shuffle, so the bound is on orientation / scale / decal mode / shading, not on the last texel."""
+    hdr, pid, st = frames(name)
+    e = TEXTURED[name]
+    assert hashlib.sha256(pid.tobytes()).hexdigest() == e["sha256_prim_id"] and [int(x) for x in st.rays] == e["rays"]
+    img8 = rt.renderer.resolve_8bit(hdr)
+    ref_blocks = np.load(os.path.join(GOLD, "ref_png_blocks_%s.npz" % name))["blocks"].astype(np.float64)
+    b = 16
+    h, w = img8.shape[0] // b * b, img8.shape[1] // b * b
+    mine = img8[:h, :w].astype(np.float64).reshape(h // b, b, w // b, b, 3).mean(axis=(1, 3))
+    d = np.abs(mine - ref_blocks).max(axis=2)
+    assert d.mean() <= max(1.0, 1.02 * e["block_mean_diff"] + 0.01), (name, d.mean())        # 8-bit levels; <= 1 for all but the Perlin scene
+    assert (d > 8).mean() <= e["blocks_off_by_8"] + 0.002, (name, (d > 8).mean())
+    assert (d > 8).mean() <= (0.06 if name == "ellipsoids_texture" else 0.01)
