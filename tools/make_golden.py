@@ -29,9 +29,9 @@ TEXTURED_PNG_SCENES = ["cube_wall", "cube_wall_normal", "cube_waves", "cube_cush
                        "ellipsoids_texture"]
 # Published renders of the sampled scenes (depth of field, area light, motion blur, glossy mirrors, a normal map at 100 spp, the
 # dielectric / conductor plates): the reference's generators are time-seeded, so only statistics can agree — block means of the
-# oracle's frame at SAMPLED_SPP samples per pixel (counter-based RNG) against the block means of the published frame.
-SAMPLED_PNG_SCENES = ["spheres_dof", "cornellbox_area", "cornellbox_boxes_dynamic", "cornellbox_brushed_metal", "sphere_normal", "metal_glass_plates"]
-SAMPLED_SPP = 16
+# oracle's frame at a few samples per pixel (counter-based RNG) against the block means of the published frame.
+SAMPLED_PNG_SCENES = {"spheres_dof": 16, "cornellbox_area": 16, "cornellbox_boxes_dynamic": 16, "cornellbox_brushed_metal": 16, "sphere_normal": 16,
+                      "metal_glass_plates": 16, "tap_0200": 4}      # tap_0200: 50k-triangle ASCII PLY mesh, dielectric, 1000x1000
 
 
 def block_means(img, b=16):
@@ -62,9 +62,9 @@ def main():
         print(name, entry)
     json.dump(digests, open(os.path.join(gold, "oracle_frames.json"), "w"), indent=1, sort_keys=True)
     textured = {}
-    for name in TEXTURED_PNG_SCENES + SAMPLED_PNG_SCENES:
+    for name in TEXTURED_PNG_SCENES + list(SAMPLED_PNG_SCENES):
         soup = rt.SceneSoup.load(os.path.join(ROOT, "scenes", name + ".npz"))
-        kw = {"num_samples": SAMPLED_SPP} if name in SAMPLED_PNG_SCENES else {}
+        kw = {"num_samples": SAMPLED_PNG_SCENES[name]} if name in SAMPLED_PNG_SCENES else {}
         hdr, pid, pt, st = orc.OracleScene(soup).render(0, nthreads=8, dynamic=True, **kw)
         img8 = rt.renderer.resolve_8bit(hdr)
         ref = np.asarray(Image.open("/root/reference/src/results/%s.png" % name).convert("RGB"), np.uint8)
