@@ -87,11 +87,22 @@ def test_oracle_vs_published_textured_png(rt, frames, name):
         hdr, pid, st = frames(name)
     assert hashlib.sha256(pid.tobytes()).hexdigest() == e["sha256_prim_id"] and [int(x) for x in st.rays] == e["rays"]
     img8 = rt.renderer.resolve_8bit(hdr)
+    if e.get("tonemapped"):
+        # the one scene with <Tonemap>: the author published an 8-bit conversion of the EXR (converter unknown).  The oracle's tone
+        # mapper on the float radiance + the scene's display gamma lands within 1.5 levels per block; on the 8-bit image (what the
+        # reference's current sources feed it, Q20) 5.8 — a plausibility bound for the operator, not a pin.
+        soup = rt.SceneSoup.load(os.path.join(ROOT, "scenes", name + ".npz"))
+        key, burn, sat, gamma = soup.tonemap
+        mapped, _ = importlib.import_module("oracle.orc").tonemap(hdr, key, burn, sat)
+        img8 = np.clip(np.power(np.clip(mapped, 0, None), 1.0 / gamma), 0, 1) * 255.0
     ref_blocks = np.load(os.path.join(GOLD, "ref_png_blocks_%s.npz" % name))["blocks"].astype(np.float64)
     b = 16
     h, w = img8.shape[0] // b * b, img8.shape[1] // b * b
     mine = img8[:h, :w].astype(np.float64).reshape(h // b, b, w // b, b, 3).mean(axis=(1, 3))
     d = np.abs(mine - ref_blocks).max(axis=2)
+    if e.get("tonemapped"):
+        assert d.mean() <= 2.0 and (d > 8).mean() <= 0.01 and abs(float(mine.mean()) - float(ref_blocks.mean())) <= 2.5
+        return
     assert d.mean() <= max(1.0, 1.02 * e["block_mean_diff"] + 0.01), (name, d.mean())        # 8-bit levels; <= 1 for all but the Perlin scene
     assert (d > 8).mean() <= e["blocks_off_by_8"] + 0.002, (name, (d > 8).mean())
     assert (d > 8).mean() <= (0.06 if name == "ellipsoids_texture" else 0.01)

@@ -76,6 +76,19 @@ def main():
                           "sha256_prim_id": hashlib.sha256(pid.tobytes()).hexdigest(), "rays": [int(x) for x in st.rays],
                           "num_samples": kw.get("num_samples", 0)}
         print(name, textured[name])
+    # cube_point_hdr: the one scene with <Tonemap>; the author published an 8-bit conversion of its EXR (converter unknown).
+    soup = rt.SceneSoup.load(os.path.join(ROOT, "scenes", "cube_point_hdr.npz"))
+    hdr, pid, pt, st = orc.OracleScene(soup).render(0, nthreads=8, dynamic=True)
+    key, burn, sat, gamma = soup.tonemap
+    mapped, params = orc.tonemap(hdr, key, burn, sat)
+    img = np.clip(np.power(np.clip(mapped, 0, None), 1.0 / gamma), 0, 1) * 255.0
+    ref = np.asarray(Image.open("/root/reference/src/results/cube_point_hdr.png").convert("RGB"), np.uint8)
+    ref_blocks = block_means(ref)
+    np.savez_compressed(os.path.join(gold, "ref_png_blocks_cube_point_hdr.npz"), blocks=ref_blocks.astype(np.float32))
+    d = np.abs(block_means(img) - ref_blocks).max(axis=2)
+    textured["cube_point_hdr"] = {"block_mean_diff": float(d.mean()), "blocks_off_by_8": float((d > 8).mean()), "tonemapped": 1,
+                                  "sha256_prim_id": hashlib.sha256(pid.tobytes()).hexdigest(), "rays": [int(x) for x in st.rays], "num_samples": 0}
+    print("cube_point_hdr", textured["cube_point_hdr"])
     json.dump(textured, open(os.path.join(gold, "oracle_textured_frames.json"), "w"), indent=1, sort_keys=True)
 
 
