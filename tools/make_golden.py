@@ -19,7 +19,8 @@ rt = importlib.import_module("ray-tracer_amd")
 from oracle import orc  # noqa: E402
 
 PNG_SCENES = ["cornellbox", "cornellbox_recursive", "simple", "spheres", "bunny", "scienceTree", "cube_point", "cube_directional",
-              "brdf_blinnphong_original", "brdf_blinnphong_modified", "brdf_phong_original", "brdf_phong_modified", "brdf_torrancesparrow"]
+              "brdf_blinnphong_original", "brdf_blinnphong_modified", "brdf_phong_original", "brdf_phong_modified", "brdf_torrancesparrow",
+              "brdf_blinnphong_modified_normalized", "brdf_phong_modified_normalized"]
 DIGEST_SCENES = PNG_SCENES + ["sphere_perlin", "sphere_perlin_bump", "cube_perlin", "cube_perlin_bump"]
 # Published renders of the reference's image-textured scenes.  Per pixel they differ from the current sources' output by sub-texel
 # amounts (older revision) and, in ellipsoids_texture, on the two Perlin-noise ellipsoids (the reference shuffles its permutation
