@@ -171,7 +171,7 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
         r.e1[0] = ab.x; r.e1[1] = ab.y; r.e1[2] = ab.z;
         r.e2[0] = ac.x; r.e2[1] = ac.y; r.e2[2] = ac.z;
         r.nrm[0] = fn.x; r.nrm[1] = fn.y; r.nrm[2] = fn.z;
-        r.object = ob; r.shape = (int32_t)t; r.kind = DEV_PRIM_TRIANGLE; r._pad = 0;
+        r.object = ob; r.shape = (int32_t)t; r.kind = DEV_PRIM_TRIANGLE; r.ill = tri_ill_conditioned(ab, ac) ? 1 : 0;
         shapeBox[t] = box_of(max3(a, max3(b, c)), min3(a, min3(b, c)));   // Triangle.cpp:68-69
     }
     {   // Mesh.cpp:88-95 + Triangle.cpp:78-105: accumulate face normals per smooth object in triangle order, then
@@ -322,6 +322,13 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
         // DFS numbering of leaves (left to right); primitive records in that order
         int wideDepth = 0;
         std::vector<int32_t> ref(bn.size(), 0);
+        // reference nodes whose range holds an ill-conditioned triangle: their children references carry DEV_REF_NOPRUNE
+        std::vector<int32_t> illPrefix((size_t)nP + 1, 0);
+        for (int64_t i = 0; i < nP; ++i) illPrefix[(size_t)i + 1] = illPrefix[(size_t)i] + (shapeRec[pshape[order[i]]].ill ? 1 : 0);
+        auto with_flag = [&](int32_t r, int32_t node) -> int32_t {
+            if (illPrefix[bn[node].end] - illPrefix[bn[node].start] == 0) return r;
+            return r >= 0 ? (r | DEV_REF_NOPRUNE) : ~(~r | DEV_REF_NOPRUNE);
+        };
         std::vector<int32_t> stack;
         stack.push_back(0);
         while (!stack.empty()) {
@@ -338,7 +345,7 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
                 }
                 lf.count = (int32_t)hs.prims.size() - lf.start;
                 // leaf reference: ~(count << 26 | start) so that the traversal needs no DevLeaf fetch; leaves that do not
-                // fit (more than 31 primitives, start >= 2^26) keep count = 0 and carry the leaf index instead
+                // fit (more than 15 primitives, start >= 2^26) keep count = 0 and carry the leaf index instead
                 if (lf.count >= 1 && lf.count <= DEV_LEAF_MAX_PACKED && lf.start < (1 << DEV_LEAF_START_BITS))
                     ref[n] = ~(int32_t)(((uint32_t)lf.count << DEV_LEAF_START_BITS) | (uint32_t)lf.start);
                 else {
@@ -403,7 +410,7 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
                     if (i < nk) {
                         const Aabb &b = bn[kids[i]].box;
                         w.minx[i] = b.lo.x; w.miny[i] = b.lo.y; w.minz[i] = b.lo.z; w.maxx[i] = b.hi.x; w.maxy[i] = b.hi.y; w.maxz[i] = b.hi.z;
-                        w.ref[i] = wref[i]; w.chain[i] = kids[i];
+                        w.ref[i] = with_flag(wref[i], kids[i]); w.chain[i] = kids[i];
                     } else {
                         w.minx[i] = w.miny[i] = w.minz[i] = 0.0f; w.maxx[i] = w.maxy[i] = w.maxz[i] = 0.0f;
                         w.ref[i] = DEV_REF_EMPTY; w.chain[i] = -1;

@@ -369,6 +369,12 @@ __global__ __launch_bounds__(256) void k_leaf_write(Tree t, int n_nodes, const i
     if (c >= 1 && c <= DEV_LEAF_MAX_PACKED && ds < (1 << DEV_LEAF_START_BITS)) leaf_ref[nd] = ~(int)(((unsigned)c << DEV_LEAF_START_BITS) | (unsigned)ds);
     else { if (li >= (1 << DEV_LEAF_START_BITS)) *status = 1; leaf_ref[nd] = ~li; }
 }
+// 1 per position of the re-ordered primitive array whose shape is an ill-conditioned triangle (DevPrim::ill); flag[n] = 0
+__global__ __launch_bounds__(256) void k_ill_flags(const int *order, const int *pshape, const float4 *shape_rec, int n, int *flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    flag[i] = i < n ? (__float_as_int(shape_rec[4 * (size_t)pshape[order[i]] + 3].w) != 0 ? 1 : 0) : 0;
+}
 __global__ __launch_bounds__(256) void k_chain(Tree t, int n_nodes, DevChain *chain) {
     const int nd = blockIdx.x * blockDim.x + threadIdx.x;
     if (nd >= n_nodes) return;
@@ -381,7 +387,7 @@ __global__ __launch_bounds__(256) void k_chain(Tree t, int n_nodes, DevChain *ch
     if (l >= 0) { chain[l].parent = nd; chain[l + 1].parent = nd; }      // distinct fields per thread: no race
 }
 // one level of the 4-wide collapse: every work item is (reference node, wide node index)
-__global__ __launch_bounds__(256) void k_collapse(Tree t, const int *leaf_ref, const int2 *work, int n_work, int2 *next_work, int *next_count,
+__global__ __launch_bounds__(256) void k_collapse(Tree t, const int *leaf_ref, const int *ill_prefix, const int2 *work, int n_work, int2 *next_work, int *next_count,
                                                 int *wide_count, DevNode4 *wide) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_work) return;
@@ -416,11 +422,13 @@ __global__ __launch_bounds__(256) void k_collapse(Tree t, const int *leaf_ref, c
             const float *b = t.box + 6 * (size_t)kids[i];
             o.minx[i] = b[0]; o.miny[i] = b[1]; o.minz[i] = b[2]; o.maxx[i] = b[3]; o.maxy[i] = b[4]; o.maxz[i] = b[5];
             o.chain[i] = kids[i];
+            // a subtree that holds an ill-conditioned triangle is never pruned by distance (DEV_REF_NOPRUNE, rt_device.h)
+            const bool keep = ill_prefix[t.end[kids[i]]] - ill_prefix[t.start[kids[i]]] > 0;
             if (t.left[kids[i]] >= 0) {
-                o.ref[i] = wbase + k_int;
+                o.ref[i] = (wbase + k_int) | (keep ? DEV_REF_NOPRUNE : 0);
                 next_work[qbase + k_int] = make_int2(kids[i], wbase + k_int);
                 ++k_int;
-            } else o.ref[i] = leaf_ref[kids[i]];
+            } else o.ref[i] = keep ? ~(~leaf_ref[kids[i]] | DEV_REF_NOPRUNE) : leaf_ref[kids[i]];
         } else {
             o.minx[i] = o.miny[i] = o.minz[i] = 0.0f; o.maxx[i] = o.maxy[i] = o.maxz[i] = 0.0f;
             o.ref[i] = DEV_REF_EMPTY; o.chain[i] = -1;
@@ -600,6 +608,10 @@ bool rt_bvh_gpu_build_flatten(const float *pbox, int64_t n64, const DevPrim *sha
             hipLaunchKernelGGL(k_leaf_write, grid_nodes, blk, 0, st, g.t, n_nodes, g.d_order, d_pshape, g.d_scan, d_dev_start, d_shape,
                                reinterpret_cast<float4 *>(out.prims), out.leaves, d_leaf_ref, d_cnt + 3);
             hipLaunchKernelGGL(k_chain, grid_nodes, blk, 0, st, g.t, n_nodes, out.chain);
+            // positions of ill-conditioned triangles, prefix-summed: a node's range [start, end) tells whether its subtree holds one
+            // (d_flag / d_scan are free again: the leaf numbering was last read by k_leaf_write)
+            hipLaunchKernelGGL(k_ill_flags, dim3((unsigned)((n + 1 + 255) / 256)), blk, 0, st, g.d_order, d_pshape, d_shape, n, g.d_flag);
+            GB_TRY(hipcub::DeviceScan::ExclusiveSum(g.d_tmp, g.tmp_bytes, g.d_flag, g.d_scan, n + 1, st));
             g.lap("leaves, records, chain");
             // wide nodes
             const int n_internal = (n_nodes - 1) / 2;                 // a full binary tree: every internal node has two children
@@ -615,7 +627,7 @@ bool rt_bvh_gpu_build_flatten(const float *pbox, int64_t n64, const DevPrim *sha
                 while (n_work > 0) {
                     ++wide_depth;
                     GB_TRY(hipMemsetAsync(d_cnt + 1, 0, sizeof(int), st));
-                    hipLaunchKernelGGL(k_collapse, dim3((n_work + 255) / 256), blk, 0, st, g.t, d_leaf_ref, d_work[cur], n_work, d_work[cur ^ 1], d_cnt + 1, d_cnt + 0, out.nodes);
+                    hipLaunchKernelGGL(k_collapse, dim3((n_work + 255) / 256), blk, 0, st, g.t, d_leaf_ref, g.d_scan, d_work[cur], n_work, d_work[cur ^ 1], d_cnt + 1, d_cnt + 0, out.nodes);
                     GB_TRY(hipMemcpyAsync(&n_work, d_cnt + 1, sizeof(int), hipMemcpyDeviceToHost, st));
                     GB_TRY(hipStreamSynchronize(st));
                     cur ^= 1;

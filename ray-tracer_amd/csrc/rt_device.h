@@ -18,7 +18,7 @@
 
 #include "../../include/rt_mi355.h"
 
-#define DEV_REF_EMPTY 0x7fffffff  // unused child slot of a DevNode4
+#define DEV_REF_EMPTY 0x3fffffff  // unused child slot of a DevNode4 (bit 30 clear: see DEV_REF_NOPRUNE)
 struct alignas(128) DevNode4 {
     float minx[4], miny[4], minz[4];   // child boxes (BVHNode::bbox of reference nodes, src/BVHTree.h:20)
     float maxx[4], maxy[4], maxz[4];
@@ -35,7 +35,10 @@ struct alignas(32) DevChain {
 static_assert(sizeof(DevChain) == 32, "DevChain must be 32 bytes");
 
 #define DEV_LEAF_START_BITS 26
-#define DEV_LEAF_MAX_PACKED 31
+#define DEV_LEAF_MAX_PACKED 15
+// Bit 30 of a DevNode4 child reference (of its complement for a leaf reference): the child's subtree holds an ill-conditioned
+// triangle (DevPrim::ill) and must never be pruned by the ray's current best t.  Stripped before the reference is used.
+#define DEV_REF_NOPRUNE 0x40000000
 struct DevLeaf {
     int32_t start, count;     // run inside DevPrim[]
 };
@@ -51,7 +54,7 @@ struct alignas(64) DevPrim {
     int32_t kind;             // DEV_PRIM_*
     int32_t shape;            // rt_hit.shape id: triangle index, or sphere index | RT_PRIM_SPHERE
     float nrm[3];             // triangle: object-space unit normal (Triangle.cpp:37)
-    int32_t _pad;
+    int32_t ill;              // 1: triangle so thin that the Cramer solution is rounding noise (rt_math.h, tri_ill_conditioned)
 };
 static_assert(sizeof(DevPrim) == 64, "DevPrim must be 64 bytes");
 

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_tri_setup(const float *vpos, const int 
     r.e1[0] = ab.x; r.e1[1] = ab.y; r.e1[2] = ab.z;
     r.e2[0] = ac.x; r.e2[1] = ac.y; r.e2[2] = ac.z;
     r.nrm[0] = fn.x; r.nrm[1] = fn.y; r.nrm[2] = fn.z;
-    r.object = tri_obj[t]; r.shape = t; r.kind = DEV_PRIM_TRIANGLE; r._pad = 0;
+    r.object = tri_obj[t]; r.shape = t; r.kind = DEV_PRIM_TRIANGLE; r.ill = tri_ill_conditioned(ab, ac) ? 1 : 0;
     rec[t] = r;
 }
 

@@ -620,6 +620,8 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
             const float mnx[4] = {q0.x, q0.y, q0.z, q0.w}, mny[4] = {q1.x, q1.y, q1.z, q1.w}, mnz[4] = {q2.x, q2.y, q2.z, q2.w};
             const float mxx[4] = {q3.x, q3.y, q3.z, q3.w}, mxy[4] = {q4.x, q4.y, q4.z, q4.w}, mxz[4] = {q5.x, q5.y, q5.z, q5.w};
             int cref[4] = {__float_as_int(q6.x), __float_as_int(q6.y), __float_as_int(q6.z), __float_as_int(q6.w)};
+            // (a reference may carry DEV_REF_NOPRUNE: the child's subtree holds an ill-conditioned triangle, whose "hit" may lie
+            // anywhere on the ray — rt_math.h, tri_ill_conditioned)
             float key[4];
             bool need_chain = false;
             int cls[4];
@@ -628,6 +630,10 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                 float tn, lb;
                 int c = slab_fast(mnx[i], mny[i], mnz[i], mxx[i], mxy[i], mxz[i], o, r, marg, amb, tn, lb);
                 if (c == 2) lb = -FLT_MAX;                        // undecided: no pruning either
+                {   // DEV_REF_NOPRUNE: strip the bit, and never skip this child because its box begins beyond the best t
+                    const int sgn = cref[i] >> 31, k = cref[i] ^ sgn;     // the reference, or the complement of a leaf reference
+                    if (k & DEV_REF_NOPRUNE) { lb = -FLT_MAX; cref[i] = (k & ~DEV_REF_NOPRUNE) ^ sgn; }
+                }
                 if (cref[i] == DEV_REF_EMPTY || lb > bound) c = 0;
                 // An undecided LEAF is decided exactly by the chain walk.  An undecided INTERNAL child of an ordinary ray (grazing
                 // its box) is simply entered: boxes nest, so that is conservative and cheap.  A ray with a zero direction component

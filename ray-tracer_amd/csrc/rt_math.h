@@ -41,6 +41,16 @@ RT_HD float comp3(f3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 
 // ---- 4x4, glm order m[col*4+row] -------------------------------------------------------------
 // mat * (x,y,z,w), vendored glm type_mat4x4.inl:526-537: (m0*x + m1*y) + (m2*z + m3*w), xyz rows only.
+// A triangle whose edges p0p1, p0p2 are (nearly) parallel: the three determinants of Triangle::Intersect (Triangle.cpp:197-240) are
+// then differences of products that cancel to rounding noise, and the reference accepts "hits" whose point lies anywhere on the
+// ray — metres outside the triangle's box (found by the fuzz sweep: a 5 x 0.005 sliver, hit point 6.4 units outside).  The
+// traversal may not prune such a primitive's box by distance.  Criterion: sin(angle between the edges) < 1e-2, or no area at all.
+RT_HD bool tri_ill_conditioned(f3 e1, f3 e2) {
+    const f3 n = cross3(e1, e2);
+    const float nn = dot3(n, n), ee = dot3(e1, e1) * dot3(e2, e2);
+    return !(nn >= 1e-4f * ee) || !(ee > 0.0f);
+}
+
 RT_HD f3 mat_mul_xyz(const float *m, float x, float y, float z, float w) {
     f3 r;
     r.x = (m[0] * x + m[4] * y) + (m[8] * z + m[12] * w);

@@ -101,3 +101,20 @@ def test_random_scene_matches_oracle(orc, gpu_ctx, seed, n_tris, depth, fancy):
     chdr, cid, ct, cst = osc.render(0, nthreads=8, num_samples=4)
     compare_frames(ghdr, chdr, gid, cid, gt, ct)
     assert list(gst.rays) == list(cst.rays)
+
+
+@pytest.mark.parametrize("host_paths", [False, True])
+def test_noise_hit_of_a_sliver_is_not_pruned(orc, gpu_ctx, host_paths, monkeypatch):
+    """Found by tools/fuzz_sweep.py (seed 12081): a 5 x 0.005 sliver whose Cramer determinants are rounding noise.  The reference
+    accepts a "hit" on it 6.4 units outside the triangle's box and closer than the ray's real hit; a traversal that prunes boxes by
+    distance never tests it.  Subtrees holding such triangles carry DEV_REF_NOPRUNE (rt_device.h) — on both builder paths."""
+    seed = 12081
+    if host_paths:
+        for k in ("RT_HOST_BUILD", "RT_HOST_FLATTEN", "RT_HOST_INGEST"):
+            monkeypatch.setenv(k, "1")
+    soup = random_scene(seed, 8000, 2, False)
+    gpu_ctx.upload(soup)
+    rays = rays_for(soup, 8000, seed)
+    g, c = gpu_ctx.intersect(rays), orc.OracleScene(soup).intersect(rays)
+    assert c["shape"][727] == 4023                      # the sliver
+    assert np.array_equal(g["shape"], c["shape"]) and np.array_equal(g["t"].view(np.uint32), c["t"].view(np.uint32))
