@@ -655,6 +655,7 @@ int rt_intersect_batch(rt_ctx *c, const rt_ray *rays, size_t n, rt_hit *hits, in
     if ((n && (!rays || !hits)) || n > 0x7fffffff) { c->error = "bad ray batch"; return RT_ERR_INVALID; }
     if (!c->has_scene) { c->error = "no scene uploaded"; return RT_ERR_NO_SCENE; }
     HIP_TRY(c, hipSetDevice(c->device));
+    if (const char *ps = getenv("RT_PRUNE_SCALE")) { c->dev.p.prune_err = c->host.params.prune_err * (float)atof(ps); c->dev.p.prune_rel = c->host.params.prune_rel * (float)atof(ps); }
     hipStream_t s = c->stream;
     const rt_ray *dr = rays; rt_hit *dh = hits;
     if (!on_device) {
