@@ -257,6 +257,18 @@ int rt_render(rt_ctx *ctx, const rt_camera_desc *camera, const rt_render_opts *o
 int rt_intersect_batch(rt_ctx *ctx, const rt_ray *rays, size_t n, rt_hit *hits, int on_device,
                        rt_stats *stats);
 
+/* rt_intersect_batch for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc): no counterpart in the reference.  Same queries and results as rt_intersect_batch(on_device = 1), but the
+ * call allocates nothing: `d_rays` / `d_hits` are DEVICE pointers the caller owns, and the traversal's scratch (the fetch
+ * counter and the stack-overflow columns) is a fixed device array inside the library, rt_noalloc_scratch_bytes() bytes
+ * (32 MiB + 256 B) per GPU for the life of the process.  hip_stream: a hipStream_t to launch on (the call then returns
+ * without waiting), or NULL for the context's stream (the call then returns after the results are complete).
+ * Limits: n <= 2^31-1; a scene whose BVH needs more stack-overflow entries per thread than the array holds for one 256-thread
+ * block (32768) is rejected with RT_ERR_TOO_LARGE; deeper trees run with proportionally fewer persistent blocks.
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two contexts) race. */
+int rt_intersect_batch_noalloc(rt_ctx *ctx, const rt_ray *d_rays, size_t n, rt_hit *d_hits, void *hip_stream);
+size_t rt_noalloc_scratch_bytes(void);
+
 /* Host-only helpers (no GPU needed). */
 
 /* Number of pixels rendered by (tile_rank, tile_world) and their row-major pixel indices in the order the

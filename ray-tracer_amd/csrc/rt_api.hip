@@ -21,9 +21,19 @@
 #include "rt_math.h"
 #include "rt_wavefront.h"
 
+// Scratch of rt_intersect_batch_noalloc: [0, NOALLOC_HEADER_INTS) counters (word 0 = the fetch counter the persistent waves
+// draw ray indices from), then the traversal-stack overflow columns.  A file-scope device array: every GPU the library runs
+// on holds its own copy at its own address until the process ends; host code only ever uses the address hipGetSymbolAddress
+// returns for the current device (g_noalloc_scratch[device]), never the array's name.
+#define NOALLOC_HEADER_INTS 64
+#define NOALLOC_OVERFLOW_INTS (8u << 20)
+static __device__ __align__(256) int scratch[NOALLOC_HEADER_INTS + NOALLOC_OVERFLOW_INTS];
+
 namespace {
 
 std::string g_create_error;
+enum { RT_MAX_DEVICES = 64 };
+int *g_noalloc_scratch[RT_MAX_DEVICES];      // per device: address of `scratch` on that device (set in rt_ctx_create)
 
 #define HIP_TRY(ctx, expr)                                                                                     \
     do {                                                                                                       \
@@ -210,6 +220,12 @@ int rt_ctx_create(int hip_device_id, rt_ctx **out) {
     if (hip_device_id < 0 || hip_device_id >= n) { g_create_error = "hip_device_id out of range"; return RT_ERR_INVALID; }
     e = hipSetDevice(hip_device_id);
     if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return RT_ERR_HIP; }
+    if (hip_device_id < RT_MAX_DEVICES && !g_noalloc_scratch[hip_device_id]) {     // once per device, with that device current
+        int *ptr = nullptr;
+        e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) { g_create_error = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e); return RT_ERR_HIP; }
+        g_noalloc_scratch[hip_device_id] = ptr;
+    }
     rt_ctx *c = new rt_ctx();
     c->device = hip_device_id;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -693,6 +709,32 @@ int rt_intersect_batch(rt_ctx *c, const rt_ray *rays, size_t n, rt_hit *hits, in
         stats->ms_kernels = stats->ms_trace = ms; stats->trace_launches = 1; stats->trace_rays = n;
         hipEventDestroy(a); hipEventDestroy(b);
     }
+    return RT_OK;
+}
+
+size_t rt_noalloc_scratch_bytes(void) { return sizeof(int) * ((size_t)NOALLOC_HEADER_INTS + NOALLOC_OVERFLOW_INTS); }
+
+int rt_intersect_batch_noalloc(rt_ctx *c, const rt_ray *d_rays, size_t n, rt_hit *d_hits, void *hip_stream) {
+    if (!c) return RT_ERR_INVALID;
+    if ((n && (!d_rays || !d_hits))) { c->error = "rt_intersect_batch_noalloc: NULL ray or hit buffer"; return RT_ERR_INVALID; }
+    if (n > 0x7fffffff) { c->error = "rt_intersect_batch_noalloc: more than 2^31-1 rays in one call"; return RT_ERR_TOO_LARGE; }
+    if (!c->has_scene) { c->error = "no scene uploaded"; return RT_ERR_NO_SCENE; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    int *ptr = c->device < RT_MAX_DEVICES ? g_noalloc_scratch[c->device] : nullptr;
+    if (!ptr) { c->error = "rt_intersect_batch_noalloc: no scratch address for this device"; return RT_ERR_INVALID; }
+    // the overflow area holds `depth` stack entries for each persistent thread: fewer blocks for a deeper tree
+    const int depth = std::max(1, c->overflow_depth), tb = rt_trace_block_threads();
+    const int64_t fit = (int64_t)NOALLOC_OVERFLOW_INTS / ((int64_t)depth * tb);
+    if (fit < 1) { c->error = "rt_intersect_batch_noalloc: the scene's BVH is too deep for the fixed scratch (stack overflow depth " + std::to_string(depth) + ")"; return RT_ERR_TOO_LARGE; }
+    const int blocks = (int)std::min<int64_t>(fit, rt_trace_resident_blocks());
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if (n) {
+        rt_launch_fill_int(s, ptr, 1, 0);        // the fetch counter starts at zero; the overflow columns need no clearing (written before read)
+        rt_launch_trace_batch(s, c->dev, d_rays, d_hits, (int)n, ptr, ptr + NOALLOC_HEADER_INTS, nullptr, blocks, blocks * tb);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { c->error = std::string("kernel launch failed: ") + hipGetErrorString(e); return RT_ERR_HIP; }
+    if (!hip_stream) HIP_TRY(c, hipStreamSynchronize(s));
     return RT_OK;
 }
 

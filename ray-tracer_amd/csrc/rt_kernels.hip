@@ -867,6 +867,17 @@ __global__ __launch_bounds__(256) void k_finalize_batch(DevScene sc, const rt_ra
     hits[i] = out;
 }
 
+__global__ void k_fill_int(int *p, int n, int v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+// a fill kernel instead of hipMemsetAsync: safe to record into a HIP graph
+void rt_launch_fill_int(hipStream_t s, int *p, int n, int v) {
+    if (n > 0) hipLaunchKernelGGL(k_fill_int, dim3((n + 255) / 256), dim3(256), 0, s, p, n, v);
+}
+int rt_trace_block_threads() { return TRACE_BLOCK; }
+int rt_trace_resident_blocks() { return NUM_CUS * TRACE_RESIDENT_PER_CU; }
+
 static int g_trace_block_cap = 0;
 void rt_set_trace_block_cap(int cap) { g_trace_block_cap = cap; }
 // Persistent grid: one block per 256 rays up to the 1024 blocks that are resident at a time (4 per CU); blocks beyond those
@@ -878,9 +889,12 @@ static int trace_blocks(int n) {
     return want < cap ? (want < 1 ? 1 : want) : cap;
 }
 template <class IO>
-static void trace_dispatch(hipStream_t s, const DevScene &sc, IO io, int n, const int *n_dev, int *fetch_counter, int *ovf, DevCounters *counters) {
-    const dim3 g(trace_blocks(n)), b(TRACE_BLOCK);
-    const int stride = rt_trace_grid_threads();
+static void trace_dispatch(hipStream_t s, const DevScene &sc, IO io, int n, const int *n_dev, int *fetch_counter, int *ovf, DevCounters *counters,
+                           int max_blocks = 0, int ovf_stride = 0) {
+    int blocks = trace_blocks(n);
+    if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
+    const dim3 g(blocks), b(TRACE_BLOCK);
+    const int stride = ovf_stride > 0 ? ovf_stride : rt_trace_grid_threads();
     const bool cnt = counters != nullptr, mot = sc.p.has_motion != 0;
     if (cnt && mot) hipLaunchKernelGGL((k_trace_generic<true, true, IO>), g, b, 0, s, sc, io, n, n_dev, fetch_counter, ovf, stride, counters);
     else if (cnt) hipLaunchKernelGGL((k_trace_generic<true, false, IO>), g, b, 0, s, sc, io, n, n_dev, fetch_counter, ovf, stride, counters);
@@ -902,10 +916,13 @@ void rt_launch_trace(hipStream_t s, const DevScene &sc, LevelBuf lv, int n_close
     else if (mot) hipLaunchKernelGGL((k_trace_generic<false, true, RenderIO>), g, b, 0, s, sc, io, io.n_closest, n_dev, fetch_counter, ovf, stride, counters);
     else hipLaunchKernelGGL((k_trace_generic<false, false, RenderIO>), g, b, 0, s, sc, io, io.n_closest, n_dev, fetch_counter, ovf, stride, counters);
 }
-void rt_launch_trace_batch(hipStream_t s, const DevScene &sc, const rt_ray *rays, rt_hit *hits, int n, int *fetch_counter, int *ovf, DevCounters *counters) {
+// max_blocks / ovf_stride (0 = defaults): a caller that brings a smaller stack-overflow area caps the persistent grid at
+// max_blocks blocks and lays the overflow columns out with ovf_stride = max_blocks * TRACE_BLOCK threads.
+void rt_launch_trace_batch(hipStream_t s, const DevScene &sc, const rt_ray *rays, rt_hit *hits, int n, int *fetch_counter, int *ovf, DevCounters *counters,
+                           int max_blocks, int ovf_stride) {
     if (n <= 0) return;
     BatchIO io; io.rays = rays; io.hits = hits;
-    trace_dispatch(s, sc, io, n, nullptr, fetch_counter, ovf, counters);
+    trace_dispatch(s, sc, io, n, nullptr, fetch_counter, ovf, counters, max_blocks, ovf_stride);
     hipLaunchKernelGGL(k_finalize_batch, dim3((n + 255) / 256), dim3(256), 0, s, sc, rays, hits, n);
 }
 

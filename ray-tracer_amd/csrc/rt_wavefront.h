@@ -78,7 +78,11 @@ void rt_launch_raygen(hipStream_t s, const DevCamera &cam, const int *pixel_list
 // One launch traces lv's n_closest rays and the shadow queue sb (length on the device, at most shadow_bound; 0 = none).
 void rt_launch_trace(hipStream_t s, const DevScene &sc, LevelBuf lv, int n_closest, ShadowBuf sb, int shadow_bound, int *fetch_counter,
                      int *overflow_stack, DevCounters *counters);
-void rt_launch_trace_batch(hipStream_t s, const DevScene &sc, const rt_ray *rays, rt_hit *hits, int n, int *fetch_counter, int *overflow_stack, DevCounters *counters);
+void rt_launch_trace_batch(hipStream_t s, const DevScene &sc, const rt_ray *rays, rt_hit *hits, int n, int *fetch_counter, int *overflow_stack, DevCounters *counters,
+                           int max_blocks = 0, int ovf_stride = 0);
+void rt_launch_fill_int(hipStream_t s, int *p, int n, int v);   // p[0..n) = v, as a kernel
+int rt_trace_block_threads();    // threads per block of the trace kernels
+int rt_trace_resident_blocks();  // blocks of the trace kernels resident on the device at a time (the grid cap)
 void rt_launch_shade_pre(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, ShadowBuf sb, LevelBuf next, int depth,
                          int *next_count);
 void rt_launch_count_kinds(hipStream_t s, LevelBuf lv, int n, ShadowBuf sb, unsigned long long *ray_kind_counts);

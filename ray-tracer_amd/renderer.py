@@ -44,6 +44,8 @@ def library():
     L.rt_scene_bvh_info.argtypes = [C.c_void_p, P(abi.BvhInfo)]
     L.rt_render.argtypes = [C.c_void_p, P(abi.CameraDesc), P(abi.RenderOpts), C.c_void_p, C.c_void_p, C.c_void_p, P(abi.Stats)]
     L.rt_intersect_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, P(abi.Stats)]
+    L.rt_intersect_batch_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.rt_noalloc_scratch_bytes.restype = C.c_size_t
     L.rt_owned_pixel_count.argtypes = [C.c_int] * 5
     L.rt_owned_pixel_count.restype = C.c_int64
     L.rt_tile_pixel_order.argtypes = [C.c_int] * 5 + [C.c_void_p]
@@ -191,6 +193,13 @@ class Context:
         self._check(self.L.rt_intersect_batch(self.h, rays.ctypes.data, len(rays), hits.ctypes.data, 0, C.byref(st) if stats else None))
         return (hits, st) if stats else hits
 
+    def intersect_device(self, rays_ptr, n, hits_ptr, noalloc=False, stream=None):
+        """Closest-hit queries on DEVICE buffers (rt_ray[n] in, rt_hit[n] out).  noalloc selects the entry point that
+        allocates nothing (fixed scratch inside the library); `stream` (a hipStream_t as int) only applies to it."""
+        if noalloc:
+            self._check(self.L.rt_intersect_batch_noalloc(self.h, rays_ptr, n, hits_ptr, stream))
+        else:
+            self._check(self.L.rt_intersect_batch(self.h, rays_ptr, n, hits_ptr, 1, None))
 
     def encode_image(self, hdr, fmt=abi.RT_IMG_PPM_P3, nx=None, ny=None, timing=False):
         """8-bit resolve + image encoding on the device (ObtainColorFromUnclampedVector, Image::SaveImageAsPPM).  `hdr` is a
