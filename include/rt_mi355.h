@@ -366,6 +366,15 @@ int rt_host_bvh_build_gpu(const rt_scene_desc *scene, int hip_device_id, rt_host
 int rt_host_bvh_info(const rt_host_bvh *bvh, rt_bvh_info *out);
 int rt_host_bvh_leaves(const rt_host_bvh *bvh, int64_t *leaf_start_end, int32_t *prim_order, float *leaf_boxes,
                        int64_t *dev_leaf_start_count, int32_t *dev_prim_shape);
+/* The pruning rule of the traversal, for tests.  A child of a 4-wide traversal node may be skipped because its box begins
+ * beyond the ray's best hit only if no triangle below it is ill-conditioned for that ray — the reference does not prune by
+ * distance at all (src/BVHTree.cpp:160-206) and its float Cramer solve (src/Triangle.cpp:186-250) puts the "hit" of a
+ * triangle that is nearly in a plane with the ray anywhere on the ray.  rt_host_bvh_cones lists, for every child of every wide
+ * node, the packed normal cone that decides this and the [start, end) range of the child's subtree in prim_order; it returns
+ * their number (either pointer may be NULL).  rt_cone_allows_prune evaluates the rule the kernels apply: 1 = a subtree
+ * with this cone word may be pruned by distance for a ray of direction[3]. */
+int64_t rt_host_bvh_cones(const rt_host_bvh *bvh, uint32_t *words, int64_t *start_end);
+int rt_cone_allows_prune(uint32_t word, const float *direction);
 void rt_host_bvh_free(rt_host_bvh *bvh);
 
 /* sizeof() of the ABI structs, in header order (0 rt_material, 1 rt_light, 2 rt_texture, 3 rt_object, 4 rt_scene_desc,

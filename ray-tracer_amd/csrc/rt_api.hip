@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "rt_build.h"
+#include "rt_cone.h"
 #include "rt_math.h"
 #include "rt_wavefront.h"
 
@@ -144,6 +145,7 @@ struct rt_ctx {
     // scene arenas
     DevArray<DevNode4> d_nodes;
     DevArray<DevChain> d_chain;
+    DevArray<int32_t> d_node_chain;
     DevArray<DevLeaf> d_leaves;
     DevArray<DevPrim> d_prims;
     DevArray<DevObject> d_objects;
@@ -188,7 +190,7 @@ struct rt_ctx {
 };
 
 static void release_all(rt_ctx *c) {
-    c->d_nodes.release(); c->d_chain.release(); c->d_leaves.release(); c->d_prims.release(); c->d_objects.release(); c->d_verts.release(); c->d_tri_vert.release();
+    c->d_nodes.release(); c->d_chain.release(); c->d_node_chain.release(); c->d_leaves.release(); c->d_prims.release(); c->d_objects.release(); c->d_verts.release(); c->d_tri_vert.release();
     c->d_materials.release(); c->d_lights.release(); c->d_textures.release(); c->d_texels.release();
     for (auto &l : c->lanes) l.release();
     c->lanes.clear();
@@ -201,6 +203,29 @@ static void release_all(rt_ctx *c) {
     c->d_img_in.release(); c->d_tm_lum.release(); c->d_tm_out.release(); c->d_tm_params.release();
     c->d_img8.release(); c->d_img_text.release(); c->d_img_tmp.release(); c->d_img_len.release(); c->d_img_off.release(); c->d_tm_partial.release();
     c->d_ply_in.release(); c->d_ply_tmp.release(); c->d_ply_pos.release(); c->d_ply_tri.release(); c->d_ply_cnt.release(); c->d_ply_off.release();
+}
+
+// Experiment switches of the traversal (thresholds of the persistent loop, pruning margin).  Only compiled into tuning builds
+// (make TUNE=1): a release library reads no such variable.  Values are clamped to what the kernel tolerates (an idle threshold
+// above 64 would never trigger a refill; a pruning scale below 1 would make pruning non-conservative) and are applied to the
+// scene's defaults on every call, so they do not outlive the variable.
+static void apply_tuning_knobs(rt_ctx *c) {
+#ifdef RT_TUNING_KNOBS
+    auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    DevSceneParams &p = c->dev.p;
+    const DevSceneParams &d = c->host.params;
+    p.tri_min_lanes = d.tri_min_lanes; p.donate = d.donate; p.refill_min_idle = d.refill_min_idle; p.donate_min_idle = d.donate_min_idle;
+    p.prune_err = d.prune_err; p.prune_rel = d.prune_rel;
+    rt_set_trace_block_cap(0);
+    if (const char *cap = getenv("RT_TRACE_BLOCK_CAP")) rt_set_trace_block_cap(std::max(0, atoi(cap)));
+    if (const char *tml = getenv("RT_TRI_MIN_LANES")) p.tri_min_lanes = clampi(atoi(tml), 1, 64);
+    if (const char *dn = getenv("RT_DONATE")) p.donate = atoi(dn) ? 1 : 0;
+    if (const char *ri = getenv("RT_REFILL_MIN_IDLE")) p.refill_min_idle = clampi(atoi(ri), 1, 64);
+    if (const char *di = getenv("RT_DONATE_MIN_IDLE")) p.donate_min_idle = clampi(atoi(di), 1, 64);
+    if (const char *ps = getenv("RT_PRUNE_SCALE")) { const float f = std::max(1.0f, (float)atof(ps)); p.prune_err = d.prune_err * f; p.prune_rel = d.prune_rel * f; }
+#else
+    (void)c;
+#endif
 }
 
 extern "C" {
@@ -266,8 +291,10 @@ int rt_scene_upload(rt_ctx *c, const rt_scene_desc *scene) {
     if (rc != RT_OK) return rc;
     HostScene &h = c->host;
     if (gs.prims) {       // built and flattened on the device (rt_bvh_gpu.hip): adopt the arrays
-        c->d_nodes.release(); c->d_chain.release(); c->d_leaves.release(); c->d_prims.release();
+        c->d_nodes.release(); c->d_chain.release(); c->d_node_chain.release(); c->d_leaves.release(); c->d_prims.release();
         c->d_nodes.p = gs.nodes; c->d_nodes.cap = (size_t)gs.n_wide;
+        c->d_node_chain.p = gs.node_chain; c->d_node_chain.cap = 4 * (size_t)gs.n_wide;
+        if (!c->d_node_chain.p) HIP_TRY(c, c->d_node_chain.ensure(4));
         c->d_chain.p = gs.chain; c->d_chain.cap = (size_t)gs.n_nodes;
         c->d_leaves.p = gs.leaves; c->d_leaves.cap = (size_t)gs.n_leaves;
         c->d_prims.p = gs.prims; c->d_prims.cap = (size_t)gs.n_leaf_prims;
@@ -275,6 +302,7 @@ int rt_scene_upload(rt_ctx *c, const rt_scene_desc *scene) {
     } else {
         UPLOAD(c, c->d_nodes, h.nodes);
         UPLOAD(c, c->d_chain, h.chain);
+        UPLOAD(c, c->d_node_chain, h.node_chain);
         UPLOAD(c, c->d_leaves, h.leaves);
         UPLOAD(c, c->d_prims, h.prims);
     }
@@ -293,7 +321,7 @@ int rt_scene_upload(rt_ctx *c, const rt_scene_desc *scene) {
     UPLOAD(c, c->d_texels, h.texels);
     DevScene &d = c->dev;
     d.p = h.params;
-    d.nodes = c->d_nodes.p; d.chain = c->d_chain.p; d.leaves = c->d_leaves.p; d.prims = c->d_prims.p; d.objects = c->d_objects.p; d.verts = c->d_verts.p;
+    d.nodes = c->d_nodes.p; d.chain = c->d_chain.p; d.node_chain = c->d_node_chain.p; d.leaves = c->d_leaves.p; d.prims = c->d_prims.p; d.objects = c->d_objects.p; d.verts = c->d_verts.p;
     d.tri_vert = c->d_tri_vert.p; d.materials = c->d_materials.p; d.lights = c->d_lights.p; d.textures = c->d_textures.p; d.texels = c->d_texels.p;
     // traversal stack overflow area: entries beyond the LDS part, one column per persistent thread
     c->overflow_depth = std::max(0, h.params.stack_bound + 2 - rt_trace_lds_stack_depth());
@@ -431,12 +459,7 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
         if (d_pt) HIP_TRY(c, hipMemsetAsync(d_pt, 0, n_out * sizeof(float), s));
     }
 
-    if (const char *cap = getenv("RT_TRACE_BLOCK_CAP")) rt_set_trace_block_cap(atoi(cap));
-    if (const char *tml = getenv("RT_TRI_MIN_LANES")) c->dev.p.tri_min_lanes = atoi(tml);
-    if (const char *dn = getenv("RT_DONATE")) c->dev.p.donate = atoi(dn);
-    if (const char *ri = getenv("RT_REFILL_MIN_IDLE")) c->dev.p.refill_min_idle = atoi(ri);
-    if (const char *di = getenv("RT_DONATE_MIN_IDLE")) c->dev.p.donate_min_idle = atoi(di);
-    if (const char *ps = getenv("RT_PRUNE_SCALE")) { c->dev.p.prune_err = c->host.params.prune_err * (float)atof(ps); c->dev.p.prune_rel = c->host.params.prune_rel * (float)atof(ps); }
+    apply_tuning_knobs(c);
     // streams
     int n_streams = opts->num_streams > 0 ? std::min<int>(opts->num_streams, RT_MAX_STREAMS) : RT_DEFAULT_STREAMS;
     int64_t batch_samples = opts->max_batch_samples > 0 ? opts->max_batch_samples : (8 << 20);     // a 4K frame at 1 spp in one batch: +11 % over two 4M batches
@@ -671,7 +694,7 @@ int rt_intersect_batch(rt_ctx *c, const rt_ray *rays, size_t n, rt_hit *hits, in
     if ((n && (!rays || !hits)) || n > 0x7fffffff) { c->error = "bad ray batch"; return RT_ERR_INVALID; }
     if (!c->has_scene) { c->error = "no scene uploaded"; return RT_ERR_NO_SCENE; }
     HIP_TRY(c, hipSetDevice(c->device));
-    if (const char *ps = getenv("RT_PRUNE_SCALE")) { c->dev.p.prune_err = c->host.params.prune_err * (float)atof(ps); c->dev.p.prune_rel = c->host.params.prune_rel * (float)atof(ps); }
+    apply_tuning_knobs(c);
     hipStream_t s = c->stream;
     const rt_ray *dr = rays; rt_hit *dh = hits;
     if (!on_device) {
@@ -1035,6 +1058,18 @@ int rt_host_bvh_leaves(const rt_host_bvh *b, int64_t *leaf_start_end, int32_t *p
     if (dev_leaf_start_count) for (size_t i = 0; i < h.leaves.size(); ++i) { dev_leaf_start_count[2 * i] = h.leaves[i].start; dev_leaf_start_count[2 * i + 1] = h.leaves[i].count; }
     if (dev_prim_shape) for (size_t i = 0; i < h.prims.size(); ++i) dev_prim_shape[i] = h.prims[i].shape;
     return RT_OK;
+}
+int64_t rt_host_bvh_cones(const rt_host_bvh *b, uint32_t *words, int64_t *start_end) {
+    if (!b) return RT_ERR_INVALID;
+    const HostScene &h = b->hs;
+    if (words) std::memcpy(words, h.cone_words.data(), h.cone_words.size() * sizeof(uint32_t));
+    if (start_end) std::memcpy(start_end, h.cone_ranges.data(), h.cone_ranges.size() * sizeof(int64_t));
+    return (int64_t)h.cone_words.size();
+}
+int rt_cone_allows_prune(uint32_t word, const float *direction) {
+    if (!direction) return 0;
+    const f3 d = ld3(direction);
+    return cone_allows_prune(word, d.x, d.y, d.z, norm3(d)) ? 1 : 0;
 }
 void rt_host_bvh_free(rt_host_bvh *b) { delete b; }
 

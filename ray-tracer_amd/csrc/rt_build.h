@@ -11,6 +11,7 @@ struct HostScene {
     DevSceneParams params;
     std::vector<DevNode4> nodes;       // 4-wide collapse of the reference tree, preorder
     std::vector<DevChain> chain;       // one per reference node (index = reference node number, preorder of the build)
+    std::vector<int32_t> node_chain;   // [4 * nodes.size()]: DevChain index of each child of each wide node
     std::vector<DevLeaf> leaves;       // DFS (left-to-right) order
     std::vector<DevPrim> prims;        // leaf order, duplicates inside one leaf removed
     std::vector<DevObject> objects;
@@ -24,6 +25,8 @@ struct HostScene {
     std::vector<int32_t> ref_prim_order;   // shape id of every reference primitive in post-partition order
     std::vector<int64_t> ref_leaf_range;   // [2*n_leaves] start,end into ref_prim_order
     std::vector<float> leaf_boxes;         // [6*n_leaves]
+    std::vector<uint32_t> cone_words;      // per child of every wide node: packed normal cone (rt_cone.h) ...
+    std::vector<int64_t> cone_ranges;      // ... and the [start, end) range of that child's subtree in ref_prim_order
     rt_bvh_info info;
     float scene_scale;                     // max |coordinate| of the root box
 };
@@ -44,6 +47,7 @@ bool rt_bvh_gpu_build(const float *pbox, int64_t n, std::vector<int32_t> &order,
 struct RtGpuScene {
     DevNode4 *nodes = nullptr;
     DevChain *chain = nullptr;
+    int32_t *node_chain = nullptr;     // [4 * n_wide]
     DevLeaf *leaves = nullptr;
     DevPrim *prims = nullptr;
     int64_t n_wide = 0, n_nodes = 0, n_leaves = 0, n_leaf_prims = 0;
@@ -56,8 +60,9 @@ struct RtGpuScene {
 };
 // Build and flatten on the GPU: shape_rec = one DevPrim per shape, pshape[i] = shape of reference primitive i; host arrays, or
 // device arrays (left untouched, still owned by the caller) when inputs_on_device is set.
-bool rt_bvh_gpu_build_flatten(const float *pbox, int64_t n, const DevPrim *shape_rec, int64_t n_shapes, const int32_t *pshape, RtGpuScene &out, std::string &err,
-                              bool inputs_on_device = false);
+// objects: the object table (host), read for the normal cones of rt_cone.h.
+bool rt_bvh_gpu_build_flatten(const float *pbox, int64_t n, const DevPrim *shape_rec, int64_t n_shapes, const int32_t *pshape, const std::vector<DevObject> &objects,
+                              RtGpuScene &out, std::string &err, bool inputs_on_device = false);
 
 // Shape setup on the device (rt_ingest.hip): triangle records, smooth vertex normals, primitive world boxes — all device memory.
 struct RtGpuIngest {

@@ -16,6 +16,7 @@
 
 #include "rt_build.h"
 #include "rt_bvh_split.h"
+#include "rt_cone.h"
 #include "rt_math.h"
 
 namespace {
@@ -46,6 +47,36 @@ struct Task {
 };
 
 constexpr int kBins = RT_BVH_BINS;
+
+// DevObject::cone_k (rt_cone.h): sigma_min^2 / sigma_max of the linear part of the object matrix, from the eigenvalues of
+// A^T A (cyclic Jacobi in double).  0 (= never prune by distance inside this object) for a matrix that is not affine.
+float cone_k_of_matrix(const float *M) {
+    if (M[3] != 0.0f || M[7] != 0.0f || M[11] != 0.0f || M[15] != 1.0f) return 0.0f;
+    double S[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double v = 0;
+            for (int r = 0; r < 3; ++r) v += (double)M[i * 4 + r] * (double)M[j * 4 + r];      // columns i and j of A
+            S[i][j] = v;
+        }
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const double off = std::fabs(S[0][1]) + std::fabs(S[0][2]) + std::fabs(S[1][2]);
+        if (!(off > 1e-300)) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (S[p][q] == 0.0) continue;
+                const double theta = (S[q][q] - S[p][p]) / (2.0 * S[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < 3; ++k) { const double a = S[k][p], b = S[k][q]; S[k][p] = c * a - sn * b; S[k][q] = sn * a + c * b; }
+                for (int k = 0; k < 3; ++k) { const double a = S[p][k], b = S[q][k]; S[p][k] = c * a - sn * b; S[q][k] = sn * a + c * b; }
+            }
+    }
+    const double lmax = std::max(S[0][0], std::max(S[1][1], S[2][2])), lmin = std::min(S[0][0], std::min(S[1][1], S[2][2]));
+    if (!(lmax > 0.0) || !(lmin > 0.0) || !std::isfinite(lmax)) return 0.0f;
+    const double k = lmin / std::sqrt(lmax) * (1.0 - 1e-4);
+    return std::isfinite(k) ? (float)k : 0.0f;
+}
 
 }  // namespace
 
@@ -94,7 +125,8 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
         bool moving = o.motion_blur[0] != 0 || o.motion_blur[1] != 0 || o.motion_blur[2] != 0;   // Shape.h:111
         q.flags = (o.flags & RT_OBJ_SMOOTH ? DEV_OBJ_SMOOTH : 0) | (o.flags & RT_OBJ_HAS_XFORM ? DEV_OBJ_HAS_XFORM : 0) |
                   (o.flags & RT_OBJ_COMPOSITE ? DEV_OBJ_COMPOSITE : 0) | (moving ? DEV_OBJ_MOTION : 0) | (mat_is_identity(Mt) ? DEV_OBJ_IDENTITY : 0);
-        q.material = o.material; q.tex_color = o.tex_color; q.tex_normal = o.tex_normal; q._pad = 0;
+        q.material = o.material; q.tex_color = o.tex_color; q.tex_normal = o.tex_normal;
+        q.cone_k = (o.flags & RT_OBJ_HAS_XFORM) ? cone_k_of_matrix(q.M) : 1.0f;
     }
 
     // ---- large scenes: shape setup, build and flattening all on the device (rt_ingest.hip, rt_bvh_gpu.hip) -----------
@@ -128,7 +160,7 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
         const int irc = rt_ingest_gpu(d, hs.objects, sphereRec, ing, err);
         if (irc < 0) return irc;
         if (irc == RT_OK) {
-            const bool ok = rt_bvh_gpu_build_flatten(ing.pbox, nP, ing.shape_rec, nT + nS, ing.pshape, *device_out, err, /*inputs_on_device=*/true);
+            const bool ok = rt_bvh_gpu_build_flatten(ing.pbox, nP, ing.shape_rec, nT + nS, ing.pshape, hs.objects, *device_out, err, /*inputs_on_device=*/true);
             if (!ok) { ing.release(); return RT_ERR_HIP; }
             device_out->verts = ing.verts; device_out->tri_vert = ing.tri_vert; device_out->n_verts = d->n_vertices; device_out->n_tris = nT;
             ing.verts = nullptr; ing.tri_vert = nullptr;
@@ -238,7 +270,7 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
     if (want_gpu && device_out && !getenv("RT_HOST_FLATTEN")) {
         // build AND flatten on the device: the traversal arrays never exist on the host
         static_assert(sizeof(Aabb) == 6 * sizeof(float), "Aabb must be six packed floats (lo, hi)");
-        if (!rt_bvh_gpu_build_flatten(reinterpret_cast<const float *>(pbox.data()), nP, shapeRec.data(), (int64_t)shapeRec.size(), pshape.data(), *device_out, err)) return RT_ERR_HIP;
+        if (!rt_bvh_gpu_build_flatten(reinterpret_cast<const float *>(pbox.data()), nP, shapeRec.data(), (int64_t)shapeRec.size(), pshape.data(), hs.objects, *device_out, err)) return RT_ERR_HIP;
         maxDepth = device_out->max_depth;
         built = device_done = true;
     }
@@ -303,8 +335,8 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
 
     lap("reference BVH build");
     // ---- flatten ------------------------------------------------------------------------------------
-    hs.nodes.clear(); hs.chain.clear(); hs.leaves.clear(); hs.prims.clear(); hs.ref_leaf_range.clear(); hs.leaf_boxes.clear();
-    hs.ref_prim_order.clear();
+    hs.nodes.clear(); hs.chain.clear(); hs.node_chain.clear(); hs.leaves.clear(); hs.prims.clear(); hs.ref_leaf_range.clear(); hs.leaf_boxes.clear();
+    hs.ref_prim_order.clear(); hs.cone_words.clear(); hs.cone_ranges.clear();
     if (!device_done) {
         hs.ref_prim_order.resize(nP);
         for (int64_t i = 0; i < nP; ++i) hs.ref_prim_order[i] = shapeRec[pshape[order[i]]].shape;
@@ -322,13 +354,19 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
         // DFS numbering of leaves (left to right); primitive records in that order
         int wideDepth = 0;
         std::vector<int32_t> ref(bn.size(), 0);
-        // reference nodes whose range holds an ill-conditioned triangle: their children references carry DEV_REF_NOPRUNE
-        std::vector<int32_t> illPrefix((size_t)nP + 1, 0);
-        for (int64_t i = 0; i < nP; ++i) illPrefix[(size_t)i + 1] = illPrefix[(size_t)i] + (shapeRec[pshape[order[i]]].ill ? 1 : 0);
-        auto with_flag = [&](int32_t r, int32_t node) -> int32_t {
-            if (illPrefix[bn[node].end] - illPrefix[bn[node].start] == 0) return r;
-            return r >= 0 ? (r | DEV_REF_NOPRUNE) : ~(~r | DEV_REF_NOPRUNE);
-        };
+        // normal cone of every reference node's subtree (rt_cone.h), bottom-up: children are created after their parent
+        std::vector<NCone> cone(bn.size());
+        for (int64_t n = (int64_t)bn.size() - 1; n >= 0; --n) {
+            if (bn[n].left >= 0) { cone[n] = cone_merge(cone[bn[n].left], cone[bn[n].right]); continue; }
+            NCone c = cone_empty();
+            for (int i = bn[n].start; i < bn[n].end; ++i) {
+                const DevPrim &rec = shapeRec[pshape[order[i]]];
+                if (rec.kind != DEV_PRIM_TRIANGLE) continue;
+                const DevObject &ob = hs.objects[rec.object];
+                c = cone_merge(c, cone_of_triangle(ld3(rec.e1), ld3(rec.e2), (ob.flags & DEV_OBJ_HAS_XFORM) ? ob.inv : nullptr, ob.cone_k));
+            }
+            cone[n] = c;
+        }
         std::vector<int32_t> stack;
         stack.push_back(0);
         while (!stack.empty()) {
@@ -406,14 +444,18 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
                 for (int i = nk - 1; i >= 0; --i)
                     if (bn[kids[i]].left >= 0) wwork.push_back(WTask{kids[i], wref[i], tk.depth + 1});
                 DevNode4 &w = hs.nodes[tk.windex];
+                if (hs.node_chain.size() < 4 * hs.nodes.size()) hs.node_chain.resize(4 * hs.nodes.size(), -1);
                 for (int i = 0; i < 4; ++i) {
                     if (i < nk) {
                         const Aabb &b = bn[kids[i]].box;
                         w.minx[i] = b.lo.x; w.miny[i] = b.lo.y; w.minz[i] = b.lo.z; w.maxx[i] = b.hi.x; w.maxy[i] = b.hi.y; w.maxz[i] = b.hi.z;
-                        w.ref[i] = with_flag(wref[i], kids[i]); w.chain[i] = kids[i];
+                        w.ref[i] = wref[i]; w.cone[i] = cone_pack(cone[kids[i]]);
+                        hs.node_chain[4 * (size_t)tk.windex + i] = kids[i];
+                        hs.cone_words.push_back(w.cone[i]); hs.cone_ranges.push_back(bn[kids[i]].start); hs.cone_ranges.push_back(bn[kids[i]].end);
                     } else {
                         w.minx[i] = w.miny[i] = w.minz[i] = 0.0f; w.maxx[i] = w.maxy[i] = w.maxz[i] = 0.0f;
-                        w.ref[i] = DEV_REF_EMPTY; w.chain[i] = -1;
+                        w.ref[i] = DEV_REF_EMPTY; w.cone[i] = RT_CONE_WORD_NEVER;
+                        hs.node_chain[4 * (size_t)tk.windex + i] = -1;
                     }
                 }
             }

@@ -25,6 +25,7 @@
 
 #include "rt_build.h"
 #include "rt_bvh_split.h"
+#include "rt_cone.h"
 
 namespace {
 
@@ -369,11 +370,28 @@ __global__ __launch_bounds__(256) void k_leaf_write(Tree t, int n_nodes, const i
     if (c >= 1 && c <= DEV_LEAF_MAX_PACKED && ds < (1 << DEV_LEAF_START_BITS)) leaf_ref[nd] = ~(int)(((unsigned)c << DEV_LEAF_START_BITS) | (unsigned)ds);
     else { if (li >= (1 << DEV_LEAF_START_BITS)) *status = 1; leaf_ref[nd] = ~li; }
 }
-// 1 per position of the re-ordered primitive array whose shape is an ill-conditioned triangle (DevPrim::ill); flag[n] = 0
-__global__ __launch_bounds__(256) void k_ill_flags(const int *order, const int *pshape, const float4 *shape_rec, int n, int *flag) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > n) return;
-    flag[i] = i < n ? (__float_as_int(shape_rec[4 * (size_t)pshape[order[i]] + 3].w) != 0 ? 1 : 0) : 0;
+// Normal cone (rt_cone.h) of every reference node of one tree level, bottom-up: a leaf merges the cones of its triangles,
+// an internal node the cones of its two children (one level deeper, already done).  cone = 5 floats per node: axis, half-angle, s.
+__device__ __forceinline__ NCone load_cone(const float *c) { NCone r; r.a = ld3(c); r.alpha = c[3]; r.smin = c[4]; return r; }
+__global__ __launch_bounds__(256) void k_cone_level(Tree t, int base, int cnt, const int *order, const int *pshape, const DevPrim *shape_rec,
+                                                   const DevObject *objects, float *cone) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= cnt) return;
+    const int nd = base + s;
+    NCone c;
+    const int l = t.left[nd];
+    if (l >= 0) c = cone_merge(load_cone(cone + 5 * (size_t)l), load_cone(cone + 5 * (size_t)(l + 1)));
+    else {
+        c = cone_empty();
+        for (int i = t.start[nd]; i < t.end[nd]; ++i) {
+            const DevPrim &rec = shape_rec[pshape[order[i]]];
+            if (rec.kind != DEV_PRIM_TRIANGLE) continue;
+            const DevObject &ob = objects[rec.object];
+            c = cone_merge(c, cone_of_triangle(ld3(rec.e1), ld3(rec.e2), (ob.flags & DEV_OBJ_HAS_XFORM) ? ob.inv : nullptr, ob.cone_k));
+        }
+    }
+    float *o = cone + 5 * (size_t)nd;
+    o[0] = c.a.x; o[1] = c.a.y; o[2] = c.a.z; o[3] = c.alpha; o[4] = c.smin;
 }
 __global__ __launch_bounds__(256) void k_chain(Tree t, int n_nodes, DevChain *chain) {
     const int nd = blockIdx.x * blockDim.x + threadIdx.x;
@@ -387,8 +405,8 @@ __global__ __launch_bounds__(256) void k_chain(Tree t, int n_nodes, DevChain *ch
     if (l >= 0) { chain[l].parent = nd; chain[l + 1].parent = nd; }      // distinct fields per thread: no race
 }
 // one level of the 4-wide collapse: every work item is (reference node, wide node index)
-__global__ __launch_bounds__(256) void k_collapse(Tree t, const int *leaf_ref, const int *ill_prefix, const int2 *work, int n_work, int2 *next_work, int *next_count,
-                                                int *wide_count, DevNode4 *wide) {
+__global__ __launch_bounds__(256) void k_collapse(Tree t, const int *leaf_ref, const float *cone, const int2 *work, int n_work, int2 *next_work, int *next_count,
+                                                int *wide_count, DevNode4 *wide, int *node_chain) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_work) return;
     const int bnode = work[w].x, windex = work[w].y;
@@ -421,17 +439,16 @@ __global__ __launch_bounds__(256) void k_collapse(Tree t, const int *leaf_ref, c
         if (i < nk) {
             const float *b = t.box + 6 * (size_t)kids[i];
             o.minx[i] = b[0]; o.miny[i] = b[1]; o.minz[i] = b[2]; o.maxx[i] = b[3]; o.maxy[i] = b[4]; o.maxz[i] = b[5];
-            o.chain[i] = kids[i];
-            // a subtree that holds an ill-conditioned triangle is never pruned by distance (DEV_REF_NOPRUNE, rt_device.h)
-            const bool keep = ill_prefix[t.end[kids[i]]] - ill_prefix[t.start[kids[i]]] > 0;
+            node_chain[4 * (size_t)windex + i] = kids[i];
+            o.cone[i] = cone_pack(load_cone(cone + 5 * (size_t)kids[i]));      // may this child be pruned by distance? (rt_cone.h)
             if (t.left[kids[i]] >= 0) {
-                o.ref[i] = (wbase + k_int) | (keep ? DEV_REF_NOPRUNE : 0);
+                o.ref[i] = wbase + k_int;
                 next_work[qbase + k_int] = make_int2(kids[i], wbase + k_int);
                 ++k_int;
-            } else o.ref[i] = keep ? ~(~leaf_ref[kids[i]] | DEV_REF_NOPRUNE) : leaf_ref[kids[i]];
+            } else o.ref[i] = leaf_ref[kids[i]];
         } else {
             o.minx[i] = o.miny[i] = o.minz[i] = 0.0f; o.maxx[i] = o.maxy[i] = o.maxz[i] = 0.0f;
-            o.ref[i] = DEV_REF_EMPTY; o.chain[i] = -1;
+            o.ref[i] = DEV_REF_EMPTY; o.cone[i] = RT_CONE_WORD_NEVER; node_chain[4 * (size_t)windex + i] = -1;
         }
     }
 }
@@ -451,6 +468,7 @@ struct GpuBuild {
     hipStream_t st = nullptr;
     bool tm = false, own_box = true;
     double t_mark = 0;
+    std::vector<std::pair<int, int>> levels;      // (first node, node count) of every tree level, root level first
     void lap(const char *what) { if (tm) { const double tn = now_ms(); fprintf(stderr, "[rt gpu build] %-24s %8.2f ms\n", what, tn - t_mark); t_mark = tn; } }
 
     bool build(const float *pbox, int n_, std::string &err, bool box_on_device = false) {
@@ -490,6 +508,7 @@ struct GpuBuild {
             hipLaunchKernelGGL(k_children, dim3(1), dim3(64), 0, st, t, d_box, d_order, d_node_of, 0, 1);      // n == 1: the root is a leaf
             while (cnt > 0) {
                 ++max_depth;
+                levels.push_back({base, cnt});
                 const dim3 grid_c((cnt + 255) / 256);
                 hipLaunchKernelGGL(k_level_init, grid_c, blk, 0, st, lv, cnt);
                 hipLaunchKernelGGL(k_reduce_boxes, grid_r, blk, 0, st, d_box, d_order, d_node_of, n, base, lv);
@@ -564,14 +583,16 @@ done:
 
 // Build AND flatten on the device: the scene arrays the traversal reads never exist on the host.  shape_rec: one 64-byte
 // DevPrim per shape (host), pshape: shape of every reference primitive (host).  On success the caller owns out.* (hipFree).
-bool rt_bvh_gpu_build_flatten(const float *pbox, int64_t n64, const DevPrim *shape_rec, int64_t n_shapes, const int32_t *pshape, RtGpuScene &out, std::string &err,
-                              bool inputs_on_device) {
+bool rt_bvh_gpu_build_flatten(const float *pbox, int64_t n64, const DevPrim *shape_rec, int64_t n_shapes, const int32_t *pshape, const std::vector<DevObject> &objects,
+                              RtGpuScene &out, std::string &err, bool inputs_on_device) {
     out = RtGpuScene();
     if (n64 <= 0) { err = "empty scene"; return false; }
     GpuBuild g;
     bool ok = g.build(pbox, (int)n64, err, inputs_on_device);
     float4 *d_shape = nullptr; int *d_pshape = nullptr, *d_uniq = nullptr, *d_dev_start = nullptr, *d_leaf_ref = nullptr, *d_cnt = nullptr;
     int2 *d_work[2] = {nullptr, nullptr};
+    float *d_cone = nullptr;
+    DevObject *d_objects = nullptr;
     if (ok) {
         const int n = g.n, n_nodes = g.n_nodes;
         hipStream_t st = g.st;
@@ -608,16 +629,21 @@ bool rt_bvh_gpu_build_flatten(const float *pbox, int64_t n64, const DevPrim *sha
             hipLaunchKernelGGL(k_leaf_write, grid_nodes, blk, 0, st, g.t, n_nodes, g.d_order, d_pshape, g.d_scan, d_dev_start, d_shape,
                                reinterpret_cast<float4 *>(out.prims), out.leaves, d_leaf_ref, d_cnt + 3);
             hipLaunchKernelGGL(k_chain, grid_nodes, blk, 0, st, g.t, n_nodes, out.chain);
-            // positions of ill-conditioned triangles, prefix-summed: a node's range [start, end) tells whether its subtree holds one
-            // (d_flag / d_scan are free again: the leaf numbering was last read by k_leaf_write)
-            hipLaunchKernelGGL(k_ill_flags, dim3((unsigned)((n + 1 + 255) / 256)), blk, 0, st, g.d_order, d_pshape, d_shape, n, g.d_flag);
-            GB_TRY(hipcub::DeviceScan::ExclusiveSum(g.d_tmp, g.tmp_bytes, g.d_flag, g.d_scan, n + 1, st));
-            g.lap("leaves, records, chain");
+            // normal cones, deepest level first
+            GB_TRY(dalloc(&d_cone, 5 * (size_t)n_nodes)); GB_TRY(dalloc(&d_objects, objects.size()));
+            if (!objects.empty()) GB_TRY(hipMemcpyAsync(d_objects, objects.data(), objects.size() * sizeof(DevObject), hipMemcpyHostToDevice, st));
+            for (size_t li = g.levels.size(); li-- > 0;) {
+                const int lbase = g.levels[li].first, lcnt = g.levels[li].second;
+                hipLaunchKernelGGL(k_cone_level, dim3((lcnt + 255) / 256), blk, 0, st, g.t, lbase, lcnt, g.d_order, d_pshape, reinterpret_cast<const DevPrim *>(d_shape),
+                                   d_objects, d_cone);
+            }
+            g.lap("leaves, records, chain, cones");
             // wide nodes
             const int n_internal = (n_nodes - 1) / 2;                 // a full binary tree: every internal node has two children
             int n_wide = 0, wide_depth = 0;
             if (n_internal > 0) {
                 GB_TRY(dalloc(&out.nodes, (size_t)n_internal));        // at most one wide node per internal reference node
+                GB_TRY(dalloc(&out.node_chain, 4 * (size_t)n_internal));
                 GB_TRY(dalloc(&d_work[0], (size_t)n_internal)); GB_TRY(dalloc(&d_work[1], (size_t)n_internal));
                 const int2 first = make_int2(0, 0);
                 const int one = 1;
@@ -627,7 +653,7 @@ bool rt_bvh_gpu_build_flatten(const float *pbox, int64_t n64, const DevPrim *sha
                 while (n_work > 0) {
                     ++wide_depth;
                     GB_TRY(hipMemsetAsync(d_cnt + 1, 0, sizeof(int), st));
-                    hipLaunchKernelGGL(k_collapse, dim3((n_work + 255) / 256), blk, 0, st, g.t, d_leaf_ref, g.d_scan, d_work[cur], n_work, d_work[cur ^ 1], d_cnt + 1, d_cnt + 0, out.nodes);
+                    hipLaunchKernelGGL(k_collapse, dim3((n_work + 255) / 256), blk, 0, st, g.t, d_leaf_ref, d_cone, d_work[cur], n_work, d_work[cur ^ 1], d_cnt + 1, d_cnt + 0, out.nodes, out.node_chain);
                     GB_TRY(hipMemcpyAsync(&n_work, d_cnt + 1, sizeof(int), hipMemcpyDeviceToHost, st));
                     GB_TRY(hipStreamSynchronize(st));
                     cur ^= 1;
@@ -652,8 +678,8 @@ bool rt_bvh_gpu_build_flatten(const float *pbox, int64_t n64, const DevPrim *sha
     }
 done:
     if (!inputs_on_device) { hipFree(d_shape); hipFree(d_pshape); }
-    hipFree(d_uniq); hipFree(d_dev_start); hipFree(d_leaf_ref); hipFree(d_cnt); hipFree(d_work[0]); hipFree(d_work[1]);
-    if (!ok) { hipFree(out.nodes); hipFree(out.chain); hipFree(out.leaves); hipFree(out.prims); out = RtGpuScene(); }
+    hipFree(d_uniq); hipFree(d_dev_start); hipFree(d_leaf_ref); hipFree(d_cnt); hipFree(d_work[0]); hipFree(d_work[1]); hipFree(d_cone); hipFree(d_objects);
+    if (!ok) { hipFree(out.nodes); hipFree(out.chain); hipFree(out.node_chain); hipFree(out.leaves); hipFree(out.prims); out = RtGpuScene(); }
     g.release();
     return ok;
 }

@@ -18,13 +18,14 @@
 
 #include "../../include/rt_mi355.h"
 
-#define DEV_REF_EMPTY 0x3fffffff  // unused child slot of a DevNode4 (bit 30 clear: see DEV_REF_NOPRUNE)
+#define DEV_REF_EMPTY 0x3fffffff  // unused child slot of a DevNode4
 struct alignas(128) DevNode4 {
     float minx[4], miny[4], minz[4];   // child boxes (BVHNode::bbox of reference nodes, src/BVHTree.h:20)
     float maxx[4], maxy[4], maxz[4];
     int32_t ref[4];                    // >= 0: DevNode4 index, < 0: leaf reference, DEV_REF_EMPTY: no child
-    int32_t chain[4];                  // DevChain index (= reference node) of each child
+    uint32_t cone[4];                  // packed normal cone of each child's subtree (rt_cone.h): may it be pruned by distance?
 };
+// (the DevChain index of each child, only needed by the rare exact walk, lives in DevScene::node_chain[4 * node + child])
 static_assert(sizeof(DevNode4) == 128, "DevNode4 must be 128 bytes");
 
 struct alignas(32) DevChain {
@@ -36,9 +37,6 @@ static_assert(sizeof(DevChain) == 32, "DevChain must be 32 bytes");
 
 #define DEV_LEAF_START_BITS 26
 #define DEV_LEAF_MAX_PACKED 15
-// Bit 30 of a DevNode4 child reference (of its complement for a leaf reference): the child's subtree holds an ill-conditioned
-// triangle (DevPrim::ill) and must never be pruned by the ray's current best t.  Stripped before the reference is used.
-#define DEV_REF_NOPRUNE 0x40000000
 struct DevLeaf {
     int32_t start, count;     // run inside DevPrim[]
 };
@@ -54,7 +52,8 @@ struct alignas(64) DevPrim {
     int32_t kind;             // DEV_PRIM_*
     int32_t shape;            // rt_hit.shape id: triangle index, or sphere index | RT_PRIM_SPHERE
     float nrm[3];             // triangle: object-space unit normal (Triangle.cpp:37)
-    int32_t ill;              // 1: triangle so thin that the Cramer solution is rounding noise (rt_math.h, tri_ill_conditioned)
+    int32_t ill;              // 1: triangle so thin that the Cramer solution is rounding noise for every ray (informational; the
+                              // traversal's pruning rule is the normal cone of rt_cone.h, which covers this case)
 };
 static_assert(sizeof(DevPrim) == 64, "DevPrim must be 64 bytes");
 
@@ -66,7 +65,8 @@ struct alignas(16) DevObject {
     float inv[16];            // Transform::invTransformationMatrix = inverse(transpose(M))
     float mblur[3];
     int32_t flags;            // DEV_OBJ_*
-    int32_t material, tex_color, tex_normal, _pad;
+    int32_t material, tex_color, tex_normal;
+    float cone_k;             // sigma_min(A)^2 / sigma_max(A) of the linear part A of M (rt_cone.h); 1 without a transform
 };
 static_assert(sizeof(DevObject) == 160, "DevObject must be 160 bytes");
 
@@ -111,6 +111,7 @@ struct DevScene {
     DevSceneParams p;
     const DevNode4 *nodes;
     const DevChain *chain;
+    const int32_t *node_chain;    // [4 * n_wide]: DevChain index (= reference node) of each child of each DevNode4
     const DevLeaf *leaves;
     const DevPrim *prims;
     const DevObject *objects;

@@ -16,6 +16,7 @@
 // Wave64 throughout; the traversal stack lives in LDS (one 4-byte column per lane, bank == lane, conflict-free).
 #include <float.h>
 
+#include "rt_cone.h"
 #include "rt_math.h"
 #include "rt_wavefront.h"
 
@@ -326,12 +327,13 @@ __device__ __noinline__ bool chain_visit(const DevChain *chain, int node, bool l
 #define CUR_WAIT 0x7ffffffc      // lane finished its own traversal and waits for parts it gave away
 #define TRACE_CHUNK 64           // rays a wave reserves per atomic
 // (thresholds: DevSceneParams::refill_min_idle / tri_min_lanes, defaults RT_REFILL_MIN_IDLE / RT_TRI_MIN_LANES in rt_device.h)
-#define LDS_PAYLOAD 14           // dwords per lane: ip.xyz, beta, gamma of the leaf-local candidate, then of the best one, then the
+#define LDS_PAYLOAD 15           // dwords per lane: ip.xyz, beta, gamma of the leaf-local candidate, then of the best one, then the
                                  // rarely used lane state below
 #define PAY_RAY_IDX 10           // index of the ray in the queue
 #define PAY_PENDING 11           // parts given away and not yet merged
 #define PAY_DY 12                // direction y, z (the hot path only needs 1/d and d.x)
 #define PAY_DZ 13
+#define PAY_DLEN 14              // |d| (normal-cone test of a child that is about to be pruned by distance)
 
 struct TraceDbg { unsigned nodes, boxes, tris, sph, v[10]; };
 
@@ -418,7 +420,8 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                 if (fin) {
                     const int ray_idx = payi[PAY_RAY_IDX * TRACE_BLOCK];
                     if (COUNT && hist) {
-                        const int bk = io.kind(ray_idx) * 16 + (ray_steps ? 32 - __clz(ray_steps) : 0);
+                        const int lg = ray_steps ? 32 - __clz(ray_steps) : 0;
+                        const int bk = io.kind(ray_idx) * 16 + (lg < 15 ? lg : 15);
                         atomicAdd(&hist[bk], 1ull);
                         atomicAdd(&hist[32 + bk], (unsigned long long)(wall_clock64() - ray_t0));     // 100 MHz ticks
                         atomicAdd(&hist[64 + bk], (unsigned long long)ray_steps);
@@ -453,7 +456,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                         f3 d;
                         if (io.load(mine, o, d, time)) {
                             payi[PAY_RAY_IDX * TRACE_BLOCK] = mine; payi[PAY_PENDING * TRACE_BLOCK] = 0;
-                            pay[PAY_DY * TRACE_BLOCK] = d.y; pay[PAY_DZ * TRACE_BLOCK] = d.z;
+                            pay[PAY_DY * TRACE_BLOCK] = d.y; pay[PAY_DZ * TRACE_BLOCK] = d.z; pay[PAY_DLEN * TRACE_BLOCK] = norm3(d);
                             dirx = d.x;
                             if (COUNT) ray_t0 = wall_clock64();
                             best_t = FLT_MAX; best_prim = -1; sp = sbase = 0; xf.id = -2; prim_i = prim_end = 0;
@@ -524,6 +527,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                             payi[PAY_RAY_IDX * TRACE_BLOCK] = payi[PAY_RAY_IDX * TRACE_BLOCK + (src - lane)];
                             pay[PAY_DY * TRACE_BLOCK] = pay[PAY_DY * TRACE_BLOCK + (src - lane)];
                             pay[PAY_DZ * TRACE_BLOCK] = pay[PAY_DZ * TRACE_BLOCK + (src - lane)];
+                            pay[PAY_DLEN * TRACE_BLOCK] = pay[PAY_DLEN * TRACE_BLOCK + (src - lane)];
                             payi[PAY_PENDING * TRACE_BLOCK] = 0;
                             best_t = bd; bound = bd; best_prim = -1;      // nothing at or beyond the giver's bound can win
                             sp = sbase = 0; xf.id = -2; prim_i = prim_end = 0;
@@ -576,9 +580,9 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
             const float4 p2 = prec[2];                       // e2.z, object, kind, shape (DevPrim, rt_device.h)
             p2x = p2.x; p_obj = __float_as_int(p2.y); p_kind = __float_as_int(p2.z);
         }
-        float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0, q6 = q0;
+        float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0, q6 = q0, q7 = q0;
         const float4 *rec = nodes4 + 8 * (size_t)(at_node ? cur : 0);
-        if (at_node) { q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3]; q4 = rec[4]; q5 = rec[5]; q6 = rec[6]; }
+        if (at_node) { q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3]; q4 = rec[4]; q5 = rec[5]; q6 = rec[6]; q7 = rec[7]; }
         // keeps the compiler from testing the primitive's kind (and waiting for it) before the node loads above are issued
         asm volatile("" : "+v"(p_kind), "+v"(p_obj) : : "memory");
         if (COUNT) { ++dbg.v[4]; if (at_node) ++dbg.v[5]; if (do_tri) ++dbg.v[7]; if (run_tri) ++dbg.v[6]; }
@@ -620,21 +624,21 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
             const float mnx[4] = {q0.x, q0.y, q0.z, q0.w}, mny[4] = {q1.x, q1.y, q1.z, q1.w}, mnz[4] = {q2.x, q2.y, q2.z, q2.w};
             const float mxx[4] = {q3.x, q3.y, q3.z, q3.w}, mxy[4] = {q4.x, q4.y, q4.z, q4.w}, mxz[4] = {q5.x, q5.y, q5.z, q5.w};
             int cref[4] = {__float_as_int(q6.x), __float_as_int(q6.y), __float_as_int(q6.z), __float_as_int(q6.w)};
-            // (a reference may carry DEV_REF_NOPRUNE: the child's subtree holds an ill-conditioned triangle, whose "hit" may lie
-            // anywhere on the ray — rt_math.h, tri_ill_conditioned)
+            const unsigned ccone[4] = {(unsigned)__float_as_int(q7.x), (unsigned)__float_as_int(q7.y), (unsigned)__float_as_int(q7.z), (unsigned)__float_as_int(q7.w)};
             float key[4];
             bool need_chain = false;
             int cls[4];
+            bool far[4], any_far = false;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float tn, lb;
                 int c = slab_fast(mnx[i], mny[i], mnz[i], mxx[i], mxy[i], mxz[i], o, r, marg, amb, tn, lb);
-                if (c == 2) lb = -FLT_MAX;                        // undecided: no pruning either
-                {   // DEV_REF_NOPRUNE: strip the bit, and never skip this child because its box begins beyond the best t
-                    const int sgn = cref[i] >> 31, k = cref[i] ^ sgn;     // the reference, or the complement of a leaf reference
-                    if (k & DEV_REF_NOPRUNE) { lb = -FLT_MAX; cref[i] = (k & ~DEV_REF_NOPRUNE) ^ sgn; }
-                }
-                if (cref[i] == DEV_REF_EMPTY || lb > bound) c = 0;
+                if (cref[i] == DEV_REF_EMPTY) c = 0;
+                // The child's box begins beyond the best hit (an undecided box never does).  It is skipped only if no triangle
+                // below it is so nearly in a plane with the ray that the reference's Cramer solve could put a "hit" anywhere
+                // on the ray (rt_cone.h) — decided after this loop, for the lanes that have such a child.
+                far[i] = c == 1 && lb > bound;
+                any_far = any_far || far[i];
                 // An undecided LEAF is decided exactly by the chain walk.  An undecided INTERNAL child of an ordinary ray (grazing
                 // its box) is simply entered: boxes nest, so that is conservative and cheap.  A ray with a zero direction component
                 // has EVERY test undecided and would walk the whole tree that way (measured: 3 s per 4K frame of config 5), so
@@ -644,6 +648,12 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                 key[i] = fminf(fmaxf(tn, 0.0f), FLT_MAX);         // NaN -> 0
             }
             if (COUNT) { ++dbg.nodes; dbg.boxes += 4; ++ray_steps; }
+            if (any_far) {
+                const float dy = pay[PAY_DY * TRACE_BLOCK], dz = pay[PAY_DZ * TRACE_BLOCK], dl = pay[PAY_DLEN * TRACE_BLOCK];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (far[i] && cone_allows_prune(ccone[i], dirx, dy, dz, dl)) cls[i] = 0;
+            }
             if (need_chain && amb < 1.0f) {
                 need_chain = false;
 #pragma unroll
@@ -655,8 +665,8 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
             }
             if (COUNT) { if (need_chain) ++dbg.v[9]; if (__any(need_chain)) ++dbg.v[8]; }
             if (need_chain) {
-                const float4 q7 = rec[7];
-                const int cch[4] = {__float_as_int(q7.x), __float_as_int(q7.y), __float_as_int(q7.z), __float_as_int(q7.w)};
+                const int4 cc4 = reinterpret_cast<const int4 *>(sc.node_chain)[cur];
+                const int cch[4] = {cc4.x, cc4.y, cc4.z, cc4.w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (cls[i] == 2)

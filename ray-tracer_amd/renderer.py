@@ -54,6 +54,9 @@ def library():
     L.rt_host_bvh_build.argtypes = [P(abi.SceneDesc), P(C.c_void_p)]
     L.rt_host_bvh_info.argtypes = [C.c_void_p, P(abi.BvhInfo)]
     L.rt_host_bvh_leaves.argtypes = [C.c_void_p] * 6
+    L.rt_host_bvh_cones.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rt_host_bvh_cones.restype = C.c_int64
+    L.rt_cone_allows_prune.argtypes = [C.c_uint32, C.c_void_p]
     L.rt_host_bvh_free.argtypes = [C.c_void_p]
     L.rt_host_bvh_free.restype = None
     L.rt_abi_sizeof.argtypes = [C.c_int]
@@ -110,7 +113,13 @@ def host_bvh(soup, gpu_device=None):
         dsc = np.zeros((info.n_leaves, 2), np.int64)
         dshape = np.zeros(info.n_leaf_prims, np.int32)
         L.rt_host_bvh_leaves(h, se.ctypes.data, order.ctypes.data, boxes.ctypes.data, dsc.ctypes.data, dshape.ctypes.data)
-        return {"info": info, "leaf_start_end": se, "prim_order": order, "leaf_boxes": boxes, "dev_leaf_start_count": dsc, "dev_prim_shape": dshape}
+        nc = L.rt_host_bvh_cones(h, None, None)
+        cw = np.zeros(max(nc, 0), np.uint32)
+        cr = np.zeros((max(nc, 0), 2), np.int64)
+        if nc > 0:
+            L.rt_host_bvh_cones(h, cw.ctypes.data, cr.ctypes.data)
+        return {"info": info, "leaf_start_end": se, "prim_order": order, "leaf_boxes": boxes, "dev_leaf_start_count": dsc, "dev_prim_shape": dshape,
+                "cone_words": cw, "cone_ranges": cr}
     finally:
         L.rt_host_bvh_free(h)
 

@@ -1,0 +1,128 @@
+"""The pruning rule of the traversal (ray-tracer_amd/csrc/rt_cone.h), checked on the CPU against its definition.
+
+The reference never prunes by distance (BVHTree.cpp:160-206); the product does, which is only safe for triangles whose Cramer
+solve (Triangle.cpp:186-250) is well conditioned for the ray.  Every child of a wide traversal node carries a packed normal cone;
+the kernels skip a far child only if rt_cone_allows_prune(word, d) holds.  Property tested here, for the host-built tree of
+several scenes: whenever the rule allows pruning, EVERY triangle in that child's subtree has
+    rho = |(e1 x e2) . d_obj| / (|e1| |e2| |d_obj|) >= 1e-2      (d_obj = the ray direction in the triangle's object space),
+evaluated independently in float64.  Directions are random and, mostly, aimed to lie almost in the plane of a triangle of the
+subtree (the case the rule exists for)."""
+import ctypes as C
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+rtp = importlib.import_module("ray-tracer_amd")
+abi = rtp.abi
+synth = importlib.import_module("ray-tracer_amd.synth")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RHO_MIN = 1e-2
+
+
+def _triangles_object_space(soup):
+    P = np.asarray(soup.vert_pos, np.float64).reshape(-1, 3)
+    T = np.asarray(soup.tri_vert).reshape(-1, 3)
+    e1 = P[T[:, 0]] - P[T[:, 1]]
+    e2 = P[T[:, 0]] - P[T[:, 2]]
+    n = np.cross(e1, e2)
+    le = np.linalg.norm(e1, axis=1) * np.linalg.norm(e2, axis=1)
+    return n, le
+
+
+def _linear_parts(soup):
+    """A (object -> world, 3x3) and its inverse per object; identity for objects without a transform."""
+    n = len(soup.objects)
+    A = np.tile(np.eye(3), (n, 1, 1))
+    for i in range(n):
+        if soup.objects["flags"][i] & abi.RT_OBJ_HAS_XFORM:
+            M = np.asarray(soup.objects["xform"][i], np.float64).reshape(4, 4).T      # glm order m[col*4+row]
+            A[i] = M[:3, :3]
+    return A, np.linalg.inv(A)
+
+
+def _check_scene(soup, seed, max_cones=400, dirs_per_cone=24):
+    L = rtp.library()
+    hb = rtp.renderer.host_bvh(soup)
+    words, ranges, order = hb["cone_words"], hb["cone_ranges"], hb["prim_order"]
+    if len(words) == 0:
+        return 0, 0
+    n_obj, le = _triangles_object_space(soup)
+    A, Ainv = _linear_parts(soup)
+    tri_obj = np.asarray(soup.tri_object)
+    rng = np.random.RandomState(seed)
+    sizes = ranges[:, 1] - ranges[:, 0]
+    pick = np.argsort(-sizes)[: max_cones // 4].tolist() + rng.choice(len(words), size=min(len(words), max_cones), replace=False).tolist()
+    allowed = checked = 0
+    for ci in pick:
+        s, e = ranges[ci]
+        shapes = order[s:e]
+        tris = np.unique(shapes[(shapes & abi.RT_PRIM_SPHERE) == 0])
+        if len(tris) == 0:
+            # spheres only: always prunable
+            d = rng.randn(3).astype(np.float32)
+            assert L.rt_cone_allows_prune(int(words[ci]), d.ctypes.data) == 1
+            continue
+        if len(tris) > 20000:
+            tris = rng.choice(tris, 20000, replace=False)
+        ob = tri_obj[tris]
+        for k in range(dirs_per_cone):
+            if k % 4 == 0:
+                d = rng.randn(3)
+            else:                                       # a world direction almost in the plane of one triangle of the subtree
+                j = rng.randint(len(tris))
+                nw = Ainv[ob[j]].T @ n_obj[tris[j]]     # world normal direction
+                nw /= max(np.linalg.norm(nw), 1e-300)
+                t = np.cross(nw, rng.randn(3)); t /= max(np.linalg.norm(t), 1e-300)
+                d = t + nw * (10.0 ** rng.uniform(-7, -0.5)) * rng.choice([-1, 1])
+            d32 = (d / np.linalg.norm(d)).astype(np.float32)
+            checked += 1
+            if not L.rt_cone_allows_prune(int(words[ci]), d32.ctypes.data):
+                continue
+            allowed += 1
+            dobj = np.einsum("nij,j->ni", Ainv[ob], d32.astype(np.float64))
+            rho = np.abs((n_obj[tris] * dobj).sum(1)) / np.maximum(le[tris] * np.linalg.norm(dobj, axis=1), 1e-300)
+            assert rho.min() >= RHO_MIN, (ci, int(s), int(e), float(rho.min()), hex(int(words[ci])))
+    return allowed, checked
+
+
+@pytest.mark.parametrize("name", ["scienceTree", "cornellbox_boxes_dynamic", "ellipsoids_texture", "bunny", "cube_waves"])
+def test_cone_rule_on_reference_scenes(name):
+    soup = rtp.SceneSoup.load(os.path.join(ROOT, "scenes", name + ".npz"))
+    allowed, checked = _check_scene(soup, 3)
+    print(name, "allowed", allowed, "of", checked)
+    # (ellipsoids_texture: its only triangles are a floor scaled 100 x 1 x 100 — condition number 100 — which is never pruned)
+    assert checked == 0 or allowed > 0 or name == "ellipsoids_texture"
+
+
+def test_cone_rule_on_knot_and_random_soup():
+    allowed, checked = _check_scene(synth.dragon_standin_scene(20000, 64, 48), 4)
+    assert allowed > checked // 10                      # a smooth mesh: most small subtrees have narrow cones
+    fz = importlib.import_module("test_gpu_fuzz")
+    a2, c2 = _check_scene(fz.random_scene(7, 3000, 2, False), 5)      # slivers, duplicates, non-uniform scale
+    assert c2 > 0
+
+
+def test_cone_word_basics():
+    L = rtp.library()
+    d = np.array([0.3, -0.5, 0.8], np.float32)
+    assert L.rt_cone_allows_prune(0, d.ctypes.data) == 1                 # k = 0: always
+    assert L.rt_cone_allows_prune(1023 << 22, d.ctypes.data) == 0       # k = 1023: never
+    for ax in np.eye(3, dtype=np.float32):
+        assert L.rt_cone_allows_prune(1023 << 22 | 1023 | 1023 << 11, ax.ctypes.data) == 0
+    # a flat quad (two coplanar triangles, normal +z): prunable for a ray 5 degrees off the plane, not for one 0.2 degrees off it
+    b = rtp.SceneBuilder()
+    m = b.add_material()
+    b.add_camera((0, 0, 5), (0, 0, -1), (0, 1, 0), (-1, 1, -1, 1), 1, 8, 8)
+    pos = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [5, 5, 5], [6, 5, 5], [5, 6, 5.5]], np.float32)
+    b.add_mesh(pos, [[0, 1, 2], [0, 2, 3], [4, 5, 6]], material=m)
+    hb = rtp.renderer.host_bvh(b.finish())
+    words, ranges, order = hb["cone_words"], hb["cone_ranges"], hb["prim_order"]
+    quad = [i for i in range(len(words)) if set(order[ranges[i, 0]:ranges[i, 1]].tolist()) <= {0, 1}]
+    assert quad
+    for i in quad:
+        for deg, want in ((5.0, 1), (0.2, 0)):
+            a = np.radians(deg)
+            d = np.array([np.cos(a) * 0.6, np.cos(a) * 0.8, np.sin(a)], np.float32)
+            assert L.rt_cone_allows_prune(int(words[i]), d.ctypes.data) == want, (deg, hex(int(words[i])))
