@@ -215,8 +215,9 @@ static void apply_tuning_knobs(rt_ctx *c) {
     DevSceneParams &p = c->dev.p;
     const DevSceneParams &d = c->host.params;
     p.tri_min_lanes = d.tri_min_lanes; p.donate = d.donate; p.refill_min_idle = d.refill_min_idle; p.donate_min_idle = d.donate_min_idle;
-    p.prune_err = d.prune_err; p.prune_rel = d.prune_rel;
+    p.prune_err = d.prune_err; p.prune_rel = d.prune_rel; p.cone_off = 0;
     rt_set_trace_block_cap(0);
+    if (const char *nc = getenv("RT_NO_CONE")) p.cone_off = atoi(nc) ? 1 : 0;
     if (const char *cap = getenv("RT_TRACE_BLOCK_CAP")) rt_set_trace_block_cap(std::max(0, atoi(cap)));
     if (const char *tml = getenv("RT_TRI_MIN_LANES")) p.tri_min_lanes = clampi(atoi(tml), 1, 64);
     if (const char *dn = getenv("RT_DONATE")) p.donate = atoi(dn) ? 1 : 0;

@@ -103,6 +103,7 @@ struct DevSceneParams {
     int32_t has_motion;       // any object with a non-zero motion-blur vector (selects the kernel instantiation)
     int32_t n_objects;
     float isect_eps_p1;       // 1 + isect_eps in float (Triangle.cpp:219): a kernel argument so that it stays in a scalar register
+    int32_t cone_off;         // tuning builds only (RT_NO_CONE): prune far children without the normal-cone test (NOT exact)
 };
 #define RT_NO_ROOT 0x7fffffff
 

@@ -652,7 +652,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                 const float dy = pay[PAY_DY * TRACE_BLOCK], dz = pay[PAY_DZ * TRACE_BLOCK], dl = pay[PAY_DLEN * TRACE_BLOCK];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (far[i] && cone_allows_prune(ccone[i], dirx, dy, dz, dl)) cls[i] = 0;
+                    if (far[i] && (sc.p.cone_off || cone_allows_prune(ccone[i], dirx, dy, dz, dl))) cls[i] = 0;
             }
             if (need_chain && amb < 1.0f) {
                 need_chain = false;
