@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 4u
+#define RT_ABI_VERSION 5u
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -195,6 +195,9 @@ typedef struct rt_stats {
     uint64_t trace_launches;      /* number of trace-kernel launches                */
     uint64_t trace_rays;          /* rays processed by those launches               */
     double ms_trace_busy;         /* time during which at least one trace launch was running (union of intervals) */
+    uint64_t level_syncs;         /* host round trips for a level's ray count between ray generation and resolve: 0 when the
+                                     frame was rendered from predicted queue sizes (every frame of a scene after its first) */
+    uint64_t frame_passes;        /* 1; 2 when a level outgrew its predicted queue and the frame was rendered again          */
 } rt_stats;
 
 typedef struct rt_ray {

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-RT_ABI_VERSION = 4
+RT_ABI_VERSION = 5
 
 RT_OK, RT_ERR_INVALID, RT_ERR_ABI, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_NO_SCENE, RT_ERR_TOO_LARGE = 0, -1, -2, -3, -4, -5, -6
 
@@ -84,7 +84,8 @@ class Stats(C.Structure):
     _fields_ = [
         ("rays", C.c_uint64 * RT_RAY_KINDS), ("node_visits", C.c_uint64), ("box_tests", C.c_uint64),
         ("tri_tests", C.c_uint64), ("sphere_tests", C.c_uint64), ("ms_total", C.c_double), ("ms_kernels", C.c_double),
-        ("ms_trace", C.c_double), ("trace_launches", C.c_uint64), ("trace_rays", C.c_uint64), ("ms_trace_busy", C.c_double)]
+        ("ms_trace", C.c_double), ("trace_launches", C.c_uint64), ("trace_rays", C.c_uint64), ("ms_trace_busy", C.c_double),
+        ("level_syncs", C.c_uint64), ("frame_passes", C.c_uint64)]
 
     def total_rays(self):
         return int(sum(self.rays))
@@ -93,7 +94,8 @@ class Stats(C.Structure):
         return {"rays": [int(x) for x in self.rays], "node_visits": int(self.node_visits), "box_tests": int(self.box_tests),
                 "tri_tests": int(self.tri_tests), "sphere_tests": int(self.sphere_tests), "ms_total": self.ms_total,
                 "ms_kernels": self.ms_kernels, "ms_trace": self.ms_trace, "trace_launches": int(self.trace_launches),
-                "trace_rays": int(self.trace_rays), "ms_trace_busy": self.ms_trace_busy}
+                "trace_rays": int(self.trace_rays), "ms_trace_busy": self.ms_trace_busy, "level_syncs": int(self.level_syncs),
+                "frame_passes": int(self.frame_passes)}
 
 
 RT_IMG_RGB8, RT_IMG_PPM_P3, RT_IMG_PPM_P6, RT_IMG_EXR_HALF = 0, 1, 2, 3

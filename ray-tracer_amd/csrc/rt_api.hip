@@ -170,6 +170,8 @@ struct rt_ctx {
     DevArray<rt_ray> d_rays;
     DevArray<rt_hit> d_hits;
     int overflow_depth = 0;
+    std::vector<double> level_ratio;        // rays per primary sample of every level in the last frame (empty: no frame of this scene yet)
+    uint64_t mispredicted_frames = 0;       // frames that had to be rendered a second time because a level outgrew its predicted queue
     std::vector<hipEvent_t> ev_pool;        // timing events, kept between frames (creating one costs several microseconds)
     size_t ev_used = 0;
     hipError_t timing_event(hipEvent_t *out) {
@@ -282,6 +284,7 @@ int rt_scene_upload(rt_ctx *c, const rt_scene_desc *scene) {
     if (!c) return RT_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     c->has_scene = false;
+    c->level_ratio.clear();
     if (scene && scene->abi_version == RT_ABI_VERSION && scene->n_spheres > 0 && scene->sph_object && scene->objects)
         for (int64_t i = 0; i < scene->n_spheres; ++i) {                 // Sphere.cpp:128 dereferences the transform unconditionally (Q9)
             const int32_t ob = scene->sph_object[i];
@@ -489,27 +492,16 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
         ln.busy = false;
     }
     HIP_TRY(c, c->d_kind.ensure(RT_RAY_KINDS));
-    HIP_TRY(c, hipMemsetAsync(c->d_kind.p, 0, RT_RAY_KINDS * sizeof(unsigned long long), s));
     DevCounters *d_counters = nullptr;
     if (stats && opts->timing >= 2) {       // timing >= 2: also count node visits / tests (slower kernels)
         HIP_TRY(c, c->d_counters.ensure(1));
-        HIP_TRY(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(DevCounters), s));
         d_counters = c->d_counters.p;
-        if (getenv("RT_TRACE_DEBUG")) {
-            static const unsigned long long one = 1;
-            HIP_TRY(c, hipMemcpyAsync(&d_counters->want_hist, &one, sizeof(one), hipMemcpyHostToDevice, s));
-        }
     }
 
     hipEvent_t ev_first = nullptr, ev_last = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;
     const bool timing = stats && opts->timing;
-    c->ev_used = 0;
-    if (timing) { HIP_TRY(c, c->timing_event(&ev_first)); HIP_TRY(c, c->timing_event(&ev_last)); HIP_TRY(c, hipEventRecord(ev_first, s)); }
     uint64_t primary_rays = 0, trace_launches = 0, trace_rays = 0;
-    // the batch streams start after the uploads / clears queued on the context stream
-    HIP_TRY(c, hipEventRecord(c->ev_ready, s));
-    for (int j = 0; j < n_streams; ++j) HIP_TRY(c, hipStreamWaitEvent(c->lanes[j].stream, c->ev_ready, 0));
 
     auto timed_trace = [&](hipStream_t st, auto launch) -> int {
         if (timing) {
@@ -523,111 +515,248 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
         return RT_OK;
     };
 
-    auto shadow_view = [&](StreamLane &ln, int k) -> ShadowBuf {
+    // counters of one batch: [child counts | fetch counters | - | shadow queue lengths], (max_depth + 2) ints each
+    auto shadow_view = [&](StreamLane &ln, int *counts, int k) -> ShadowBuf {
         StreamLane::ShadowMem &m = ln.sh[k & 1];
         ShadowBuf sb;
         sb.o = m.o.p; sb.d = m.d.p; sb.ipref = m.ip.p; sb.ldir = m.ldir.p; sb.occluded = m.occ.p;
-        sb.count = ln.d_counts.p + 3 * (max_depth + 2) + k;
+        sb.count = counts + 3 * (max_depth + 2) + k;
         sb.capacity = (int)std::min<size_t>(m.o.cap, 0x7fffffff);
         return sb;
     };
     auto shadow_bound = [&](StreamLane &ln, int k) -> int { return nl > 0 ? ln.levels[k].count * nl : 0; };
     // After the last level: its shadow rays, its lighting, then the backward sweep and the resolve of the batch.
-    auto finish_batch = [&](StreamLane &ln, int last) -> int {
+    // dev: the lengths of levels >= 1 are device counters (levels[k].count is then the bound they were sized with).
+    auto finish_batch = [&](StreamLane &ln, int *counts, int last, bool dev) -> int {
         hipStream_t st = ln.stream;
-        const ShadowBuf sb = shadow_view(ln, last);
+        auto ndev = [&](int k) -> const int * { return dev && k > 0 ? counts + k : nullptr; };
+        const ShadowBuf sb = shadow_view(ln, counts, last);
         const int bound = shadow_bound(ln, last);
         if (bound > 0) {
-            int rc = timed_trace(st, [&] { rt_launch_trace(st, c->dev, ln.levels[last].view(), 0, sb, bound, ln.d_counts.p + (max_depth + 2) + last + 1, ln.d_overflow.p, d_counters); });
+            int rc = timed_trace(st, [&] { rt_launch_trace(st, c->dev, ln.levels[last].view(), 0, nullptr, sb, bound, counts + (max_depth + 2) + last + 1, ln.d_overflow.p, d_counters); });
             if (rc != RT_OK) return rc;
-            ++trace_launches; trace_rays += (uint64_t)bound;
+            ++trace_launches;
+            if (!dev) trace_rays += (uint64_t)bound;
         }
-        rt_launch_shade_post(st, c->dev, dc, ln.levels[last].view(), ln.levels[last].count, sb);
+        rt_launch_shade_post(st, c->dev, dc, ln.levels[last].view(), ln.levels[last].count, ndev(last), sb);
         for (int k = last; k >= 0; --k)
-            rt_launch_backward(st, ln.levels[k].view(), ln.levels[k].count, ln.levels[k + 1].view(), (k < last) ? 1 : 0);
+            rt_launch_backward(st, ln.levels[k].view(), ln.levels[k].count, ndev(k), ln.levels[k + 1].view(), (k < last) ? 1 : 0);
         rt_launch_resolve(st, dc, c->d_pixels.p, (int)ln.p0, ln.np, ln.levels[0].view(), compact ? 1 : 0, d_hdr, d_pid, d_pt);
         ln.busy = false;
         return RT_OK;
     };
     // Level ln.k: ONE trace launch for its closest-hit rays and the shadow rays of level k-1, then the lighting of level
-    // k-1 and the surface pass of level k (shadow rays + children).  Leaves the lane waiting for the child count, or
-    // finishes the batch at the last level.
-    auto enqueue_level = [&](StreamLane &ln) -> int {
+    // k-1 and the surface pass of level k (shadow rays + children).  Host-counted mode (dev = false): leaves the lane waiting
+    // for the child count, or finishes the batch at the last level.
+    auto enqueue_level = [&](StreamLane &ln, int *counts, bool dev, int next_cap) -> int {
         const int k = ln.k;
         hipStream_t st = ln.stream;
         LevelMem &lm = ln.levels[k];
         const int n = lm.count;
-        int *counts = ln.d_counts.p;
-        const ShadowBuf sb_prev = shadow_view(ln, k > 0 ? k - 1 : 1);
+        auto ndev = [&](int q) -> const int * { return dev && q > 0 ? counts + q : nullptr; };
+        const ShadowBuf sb_prev = shadow_view(ln, counts, k > 0 ? k - 1 : 1);
         const int bound_prev = k > 0 ? shadow_bound(ln, k - 1) : 0;
-        int rc = timed_trace(st, [&] { rt_launch_trace(st, c->dev, lm.view(), n, sb_prev, bound_prev, counts + (max_depth + 2) + k, ln.d_overflow.p, d_counters); });
+        int rc = timed_trace(st, [&] { rt_launch_trace(st, c->dev, lm.view(), n, ndev(k), sb_prev, bound_prev, counts + (max_depth + 2) + k, ln.d_overflow.p, d_counters); });
         if (rc != RT_OK) return rc;
-        ++trace_launches; trace_rays += (uint64_t)n + (uint64_t)bound_prev;
-        const size_t nsh = (size_t)n * (size_t)std::max(1, nl);
-        if (nsh > 0x3fffffff) { c->error = "shadow queue too large; lower max_batch_samples"; return RT_ERR_TOO_LARGE; }
-        HIP_TRY(c, ln.sh[k & 1].ensure(nsh));
+        ++trace_launches;
+        if (!dev) trace_rays += (uint64_t)n + (uint64_t)bound_prev;
         LevelMem &nx = ln.levels[k + 1];
-        nx.count = 0;
-        if (k < max_depth) {
-            if ((size_t)n * 2 > 0x3fffffff) { c->error = "ray queue too large; lower max_batch_samples"; return RT_ERR_TOO_LARGE; }
-            HIP_TRY(c, nx.ensure((size_t)n * 2));
-        }
-        rt_launch_shade_pre(st, c->dev, dc, lm.view(), n, shadow_view(ln, k), nx.view(), k, counts + k + 1);
-        if (k < max_depth) {
+        LevelBuf nxv;
+        if (!dev) {
+            const size_t nsh = (size_t)n * (size_t)std::max(1, nl);
+            if (nsh > 0x3fffffff) { c->error = "shadow queue too large; lower max_batch_samples"; return RT_ERR_TOO_LARGE; }
+            HIP_TRY(c, ln.sh[k & 1].ensure(nsh));
+            nx.count = 0;
+            if (k < max_depth) {
+                if ((size_t)n * 2 > 0x3fffffff) { c->error = "ray queue too large; lower max_batch_samples"; return RT_ERR_TOO_LARGE; }
+                HIP_TRY(c, nx.ensure((size_t)n * 2));
+            }
+            nxv = nx.view();
+        } else { nxv = nx.view(); nxv.capacity = next_cap; }     // buffers were sized before the batch started
+        rt_launch_shade_pre(st, c->dev, dc, lm.view(), n, ndev(k), shadow_view(ln, counts, k), nxv, k, counts + k + 1);
+        if (!dev && k < max_depth) {
             HIP_TRY(c, hipMemcpyAsync(ln.h_count, counts + k + 1, sizeof(int), hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipEventRecord(ln.ev_count, st));
         }
         // the ray statistics of level k and the lighting of level k-1 (which needs only this launch's shadow results) are queued
         // AFTER the count copy: they keep the GPU busy while the host makes its round trip for the child count (measured gap
         // without them: 21-27 us per level)
-        if (stats) rt_launch_count_kinds(st, lm.view(), n, shadow_view(ln, k), c->d_kind.p);
-        if (k > 0) rt_launch_shade_post(st, c->dev, dc, ln.levels[k - 1].view(), ln.levels[k - 1].count, sb_prev);
-        if (k < max_depth) return RT_OK;       // lane stays busy, waiting for the count
-        return finish_batch(ln, k);
+        if (stats) rt_launch_count_kinds(st, lm.view(), n, ndev(k), shadow_view(ln, counts, k), c->d_kind.p);
+        if (k > 0) rt_launch_shade_post(st, c->dev, dc, ln.levels[k - 1].view(), ln.levels[k - 1].count, ndev(k - 1), sb_prev);
+        return RT_OK;
     };
 
-    int64_t next_p0 = 0;
-    for (;;) {
-        bool any = false;
+    // What the levels of a batch held, as a fraction of its primary samples: the next frame sizes its queues and launches from
+    // these (c->level_ratio), so that no level length has to travel to the host between raygen and resolve.
+    std::vector<double> seen_ratio((size_t)max_depth + 2, 0.0);
+    auto note_counts = [&](int n0, const int *level_count) {
+        for (int k = 1; k <= max_depth + 1; ++k) seen_ratio[(size_t)k] = std::max(seen_ratio[(size_t)k], n0 > 0 ? (double)level_count[k] / (double)n0 : 0.0);
+    };
+
+    // One pass over the frame.  predicted = false: the host reads every level's child count before it sizes and launches the
+    // next level (one round trip per level and batch).  predicted = true: sizes and launch bounds come from the previous frame
+    // of this scene; lengths stay on the device; a level that outgrows its queue drops the excess children and the pass
+    // returns 1 (the caller then renders the frame again, host-counted).
+    uint64_t level_syncs = 0, frame_passes = 0;
+    // the context stream continues after every batch stream has drained; the end of the frame's kernels for the timing
+    auto drain_lanes = [&]() -> hipError_t {
         for (int j = 0; j < n_streams; ++j) {
-            StreamLane &ln = c->lanes[j];
-            if (!ln.busy) {
-                if (next_p0 >= n_owned) continue;
-                // start the next batch on this stream
+            hipError_t e = hipEventRecord(c->lanes[j].ev_done, c->lanes[j].stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(s, c->lanes[j].ev_done, 0);
+            if (e != hipSuccess) return e;
+        }
+        return timing ? hipEventRecord(ev_last, s) : hipSuccess;
+    };
+    auto run_frame = [&](bool predicted) -> int {
+        ++frame_passes;
+        HIP_TRY(c, hipMemsetAsync(c->d_kind.p, 0, RT_RAY_KINDS * sizeof(unsigned long long), s));
+        if (d_counters) {
+            HIP_TRY(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(DevCounters), s));
+            if (getenv("RT_TRACE_DEBUG")) {
+                static const unsigned long long one = 1;
+                HIP_TRY(c, hipMemcpyAsync(&d_counters->want_hist, &one, sizeof(one), hipMemcpyHostToDevice, s));
+            }
+        }
+        trace_events.clear();
+        c->ev_used = 0;
+        primary_rays = trace_launches = trace_rays = 0;
+        std::fill(seen_ratio.begin(), seen_ratio.end(), 0.0);
+        if (timing) { HIP_TRY(c, c->timing_event(&ev_first)); HIP_TRY(c, c->timing_event(&ev_last)); HIP_TRY(c, hipEventRecord(ev_first, s)); }
+        // the batch streams start after the uploads / clears queued on the context stream
+        HIP_TRY(c, hipEventRecord(c->ev_ready, s));
+        for (int j = 0; j < n_streams; ++j) { HIP_TRY(c, hipStreamWaitEvent(c->lanes[j].stream, c->ev_ready, 0)); c->lanes[j].busy = false; }
+        int64_t next_p0 = 0;
+        if (predicted) {
+            const int64_t n_batches = (n_owned + batch_pixels - 1) / batch_pixels;
+            const size_t slots = (size_t)((n_batches + n_streams - 1) / n_streams);
+            struct Rec { int lane, slot, n0; std::vector<int> est; };
+            std::vector<Rec> recs;
+            for (int j = 0; j < n_streams; ++j) HIP_TRY(c, c->lanes[j].d_counts.ensure(n_cnt * std::max<size_t>(1, slots)));
+            for (int64_t b = 0; b < n_batches; ++b) {
+                StreamLane &ln = c->lanes[(size_t)(b % n_streams)];
+                const int slot = (int)(b / n_streams);
+                int *counts = ln.d_counts.p + (size_t)slot * n_cnt;
                 ln.p0 = next_p0;
                 ln.np = (int)std::min<int64_t>(batch_pixels, n_owned - next_p0);
                 next_p0 += ln.np;
                 const int n0 = ln.np * spp;
                 primary_rays += (uint64_t)n0;
-                HIP_TRY(c, ln.levels[0].ensure((size_t)n0));
-                ln.levels[0].count = n0;
+                // bounds of every level from the previous frame's ratios (+ 1/16 + 4096), never above what the level above can spawn
+                Rec rec; rec.lane = (int)(b % n_streams); rec.slot = slot; rec.n0 = n0;
+                rec.est.assign((size_t)max_depth + 2, 0);
+                rec.est[0] = n0;
+                for (int k = 1; k <= max_depth; ++k) {
+                    const double r = c->level_ratio[(size_t)k];
+                    if (!(r > 0.0) || rec.est[(size_t)k - 1] == 0) break;
+                    const double want = r * (double)n0 * 1.0625 + 4096.0;
+                    rec.est[(size_t)k] = (int)std::min<double>(std::min<double>(want, 2.0 * (double)rec.est[(size_t)k - 1]), (double)0x3fffffff);
+                }
+                int last = 0;
+                for (int k = 0; k <= max_depth; ++k) {
+                    if (rec.est[(size_t)k] == 0) break;
+                    last = k;
+                    HIP_TRY(c, ln.levels[(size_t)k].ensure((size_t)rec.est[(size_t)k]));
+                    ln.levels[(size_t)k].count = rec.est[(size_t)k];
+                    const size_t nsh = (size_t)rec.est[(size_t)k] * (size_t)std::max(1, nl);
+                    if (nsh > 0x3fffffff) { c->error = "shadow queue too large; lower max_batch_samples"; return RT_ERR_TOO_LARGE; }
+                    HIP_TRY(c, ln.sh[k & 1].ensure(nsh));
+                }
+                ln.levels[(size_t)last + 1].count = 0;
                 rt_launch_raygen(ln.stream, dc, c->d_pixels.p, (int)ln.p0, n0, ln.levels[0].view());
-                HIP_TRY(c, hipMemsetAsync(ln.d_counts.p, 0, n_cnt * sizeof(int), ln.stream));
-                ln.k = 0;
-                ln.busy = true;
-                int rc = enqueue_level(ln);
+                rt_launch_fill_int(ln.stream, counts, (int)n_cnt, 0);
+                for (int k = 0; k <= last; ++k) {
+                    ln.k = k;
+                    int rc = enqueue_level(ln, counts, true, k < last ? rec.est[(size_t)k + 1] : 0);
+                    if (rc != RT_OK) return rc;
+                }
+                int rc = finish_batch(ln, counts, last, true);
                 if (rc != RT_OK) return rc;
-                any = true;
-                continue;
+                recs.push_back(std::move(rec));
             }
-            // the lane waits for the child count of level ln.k
-            any = true;
-            HIP_TRY(c, hipEventSynchronize(ln.ev_count));
-            const int child_count = *ln.h_count;
-            ln.levels[ln.k + 1].count = child_count;
-            int rc;
-            if (child_count == 0) rc = finish_batch(ln, ln.k);
-            else { ++ln.k; rc = enqueue_level(ln); }
-            if (rc != RT_OK) return rc;
+            HIP_TRY(c, drain_lanes());
+            // one read-back per frame: every batch's counters, after the streams have drained
+            std::vector<std::vector<int>> host_counts((size_t)n_streams);
+            for (int j = 0; j < n_streams; ++j) {
+                host_counts[(size_t)j].resize(n_cnt * std::max<size_t>(1, slots));
+                HIP_TRY(c, hipMemcpyAsync(host_counts[(size_t)j].data(), c->lanes[j].d_counts.p, host_counts[(size_t)j].size() * sizeof(int), hipMemcpyDeviceToHost, c->lanes[j].stream));
+            }
+            for (int j = 0; j < n_streams; ++j) HIP_TRY(c, hipStreamSynchronize(c->lanes[j].stream));
+            bool overflow = false;
+            for (const Rec &r : recs) {
+                const int *hc = host_counts[(size_t)r.lane].data() + (size_t)r.slot * n_cnt;
+                for (int k = 1; k <= max_depth + 1; ++k) overflow = overflow || hc[k] > r.est[(size_t)k];
+                note_counts(r.n0, hc);
+                trace_rays += (uint64_t)r.n0;
+                for (int k = 1; k <= max_depth; ++k) trace_rays += (uint64_t)std::max(0, hc[k]);
+                for (int k = 0; k <= max_depth; ++k) trace_rays += (uint64_t)std::max(0, hc[3 * (max_depth + 2) + k]);
+            }
+            return overflow ? 1 : RT_OK;
         }
-        if (!any) break;
+        std::vector<int> cur_counts((size_t)n_streams * ((size_t)max_depth + 2), 0);
+        for (;;) {
+            bool any = false;
+            for (int j = 0; j < n_streams; ++j) {
+                StreamLane &ln = c->lanes[j];
+                int *lane_counts = cur_counts.data() + (size_t)j * ((size_t)max_depth + 2);
+                auto batch_done = [&]() { note_counts(ln.np * spp, lane_counts); };
+                if (!ln.busy) {
+                    if (next_p0 >= n_owned) continue;
+                    // start the next batch on this stream
+                    ln.p0 = next_p0;
+                    ln.np = (int)std::min<int64_t>(batch_pixels, n_owned - next_p0);
+                    next_p0 += ln.np;
+                    const int n0 = ln.np * spp;
+                    primary_rays += (uint64_t)n0;
+                    HIP_TRY(c, ln.levels[0].ensure((size_t)n0));
+                    ln.levels[0].count = n0;
+                    std::fill(lane_counts, lane_counts + max_depth + 2, 0);
+                    rt_launch_raygen(ln.stream, dc, c->d_pixels.p, (int)ln.p0, n0, ln.levels[0].view());
+                    HIP_TRY(c, hipMemsetAsync(ln.d_counts.p, 0, n_cnt * sizeof(int), ln.stream));
+                    ln.k = 0;
+                    ln.busy = true;
+                    int rc = enqueue_level(ln, ln.d_counts.p, false, 0);
+                    if (rc == RT_OK && max_depth == 0) { rc = finish_batch(ln, ln.d_counts.p, 0, false); batch_done(); }
+                    if (rc != RT_OK) return rc;
+                    any = true;
+                    continue;
+                }
+                // the lane waits for the child count of level ln.k
+                any = true;
+                HIP_TRY(c, hipEventSynchronize(ln.ev_count));
+                ++level_syncs;
+                const int child_count = *ln.h_count;
+                ln.levels[ln.k + 1].count = child_count;
+                lane_counts[ln.k + 1] = child_count;
+                int rc;
+                if (child_count == 0) { rc = finish_batch(ln, ln.d_counts.p, ln.k, false); batch_done(); }
+                else {
+                    ++ln.k;
+                    rc = enqueue_level(ln, ln.d_counts.p, false, 0);
+                    if (rc == RT_OK && ln.k == max_depth) { rc = finish_batch(ln, ln.d_counts.p, ln.k, false); batch_done(); }
+                }
+                if (rc != RT_OK) return rc;
+            }
+            if (!any) break;
+        }
+        HIP_TRY(c, drain_lanes());
+        return RT_OK;
+    };
+
+    const bool can_predict = c->level_ratio.size() == (size_t)max_depth + 2 && !getenv("RT_HOST_COUNTS");
+    int frc = run_frame(can_predict);
+    if (frc == 1) {
+        // a level outgrew the queue its prediction had sized (new camera, other sample count ...): once more, host-counted
+        for (int j = 0; j < n_streams; ++j) HIP_TRY(c, hipStreamSynchronize(c->lanes[j].stream));
+        ++c->mispredicted_frames;
+        frc = run_frame(false);
     }
-    // the context stream continues after every batch stream has drained
-    for (int j = 0; j < n_streams; ++j) {
-        HIP_TRY(c, hipEventRecord(c->lanes[j].ev_done, c->lanes[j].stream));
-        HIP_TRY(c, hipStreamWaitEvent(s, c->lanes[j].ev_done, 0));
+    if (frc != RT_OK) {
+        // leave no launch of a failed frame in flight: they write caller-owned buffers and the context's queues
+        for (int j = 0; j < n_streams; ++j) if (c->lanes[j].stream) hipStreamSynchronize(c->lanes[j].stream);
+        hipStreamSynchronize(s);
+        return frc;
     }
-    if (timing) HIP_TRY(c, hipEventRecord(ev_last, s));
+    c->level_ratio = seen_ratio;
     if (!opts->output_on_device) {
         HIP_TRY(c, hipMemcpyAsync(hdr_rgb, d_hdr, 3 * n_out * sizeof(float), hipMemcpyDeviceToHost, s));
         if (prim_id) HIP_TRY(c, hipMemcpyAsync(prim_id, d_pid, n_out * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -661,7 +790,10 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
                 fprintf(stderr, "\n");
             }
         }
-        stats->trace_launches = trace_launches; stats->trace_rays = trace_rays;
+        stats->trace_launches = trace_launches;
+        stats->trace_rays = stats->rays[RT_RAY_PRIMARY] + stats->rays[RT_RAY_SHADOW] + stats->rays[RT_RAY_REFLECT] + stats->rays[RT_RAY_REFRACT];
+        (void)trace_rays;
+        stats->level_syncs = level_syncs; stats->frame_passes = frame_passes;
         if (timing) {
             float ms = 0;
             hipEventElapsedTime(&ms, ev_first, ev_last);

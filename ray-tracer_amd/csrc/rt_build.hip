@@ -471,6 +471,7 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
     hs.params.bg_texture = d->bg_texture;
     hs.params.n_lights = d->n_lights; hs.params.n_materials = d->n_materials; hs.params.n_textures = d->n_textures;
     hs.params.bvh_depth = maxDepth;
+    hs.params.flt_max = 3.402823466e+38f;
     hs.params.tri_min_lanes = RT_TRI_MIN_LANES;
     hs.params.donate = 1;
     hs.params.refill_min_idle = RT_REFILL_MIN_IDLE;

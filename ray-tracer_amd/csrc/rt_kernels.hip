@@ -58,6 +58,24 @@ __device__ __forceinline__ double uni(double u, double a, double b) { return u *
 // ====================================================================================================
 // Traversal
 // ====================================================================================================
+typedef __attribute__((address_space(3))) int lds_int;
+typedef __attribute__((address_space(3))) float lds_float;
+// rt_math.h's mat * (x, y, z, w) and transpose(mat) * (x, y, z, w) for a matrix in LDS (same association)
+__device__ __forceinline__ f3 mat_mul_xyz(const lds_float *m, float x, float y, float z, float w) {
+    f3 r;
+    r.x = (m[0] * x + m[4] * y) + (m[8] * z + m[12] * w);
+    r.y = (m[1] * x + m[5] * y) + (m[9] * z + m[13] * w);
+    r.z = (m[2] * x + m[6] * y) + (m[10] * z + m[14] * w);
+    return r;
+}
+__device__ __forceinline__ f3 matT_mul_xyz(const lds_float *m, float x, float y, float z, float w) {
+    f3 r;
+    r.x = (m[0] * x + m[1] * y) + (m[2] * z + m[3] * w);
+    r.y = (m[4] * x + m[5] * y) + (m[6] * z + m[7] * w);
+    r.z = (m[8] * x + m[9] * y) + (m[10] * z + m[11] * w);
+    return r;
+}
+
 struct Cand {
     float t;       // x-only world parameter (Q2)
     f3 ip;         // world intersection point
@@ -103,9 +121,9 @@ __device__ __noinline__ void enter_object_motion(const DevScene &sc, int obj, f3
 #define OBJ_CACHE 24
 #define OBJ_CACHE_DWORDS 33
 template <bool MOTION>
-__device__ __forceinline__ void enter_object(const DevScene &sc, const float *objc, int obj, f3 o, f3 d, float time, ObjXf &x) {
+__device__ __forceinline__ void enter_object(const DevScene &sc, const lds_float *objc, int obj, f3 o, f3 d, float time, ObjXf &x) {
     if (obj < OBJ_CACHE) {
-        const float *c = objc + obj * OBJ_CACHE_DWORDS;
+        const lds_float *c = objc + obj * OBJ_CACHE_DWORDS;
         const int flags = __float_as_int(c[32]);
         if (!(MOTION && (flags & DEV_OBJ_HAS_XFORM) && (flags & DEV_OBJ_MOTION))) {
             x.id = obj;
@@ -153,9 +171,9 @@ __device__ __forceinline__ f3 object_point_to_world_far(const DevObject *objects
     return mat_mul_xyz(M, p.x, p.y, p.z, 1.0f);
 }
 template <bool MOTION>
-__device__ __forceinline__ f3 object_point_to_world(const DevScene &sc, const float *objc, int obj, float time, f3 p) {
+__device__ __forceinline__ f3 object_point_to_world(const DevScene &sc, const lds_float *objc, int obj, float time, f3 p) {
     if (obj < OBJ_CACHE) {
-        const float *c = objc + obj * OBJ_CACHE_DWORDS;
+        const lds_float *c = objc + obj * OBJ_CACHE_DWORDS;
         if (!MOTION || !(__float_as_int(c[32]) & DEV_OBJ_MOTION)) return mat_mul_xyz(c, p.x, p.y, p.z, 1.0f);
     }
     return object_point_to_world_far<MOTION>(sc.objects, obj, time, p);
@@ -168,7 +186,7 @@ __device__ __forceinline__ float det3(float ax, float ay, float az, float bx, fl
 
 // Triangle::Intersect up to the world-space t (Triangle.cpp:115-135, 186-250; Q2, Q6, Q8)
 template <bool MOTION>
-__device__ __forceinline__ bool hit_triangle(const DevScene &sc, const float *objc, const float4 q0, const float4 q1, const float q2x, const ObjXf &x, float wox, float wdx,
+__device__ __forceinline__ bool hit_triangle(const DevScene &sc, const lds_float *objc, const float4 q0, const float4 q1, const float q2x, const ObjXf &x, float wox, float wdx,
                                              float time, float eps, float err, Cand &c) {
     const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2x);
     const f3 d = x.d;
@@ -203,7 +221,7 @@ __device__ __forceinline__ bool sphere_t(f3 center, float radius, f3 o, f3 d, fl
     return t > 0;
 }
 template <bool MOTION>
-__device__ __forceinline__ bool hit_sphere(const DevScene &sc, const float *objc, const float4 q0, const ObjXf &x, float wox, float wdx, float time, Cand &c) {
+__device__ __forceinline__ bool hit_sphere(const DevScene &sc, const lds_float *objc, const float4 q0, const ObjXf &x, float wox, float wdx, float time, Cand &c) {
     float t;
     if (!sphere_t(mk3(q0.x, q0.y, q0.z), q0.w, x.o, x.d, t)) return false;
     f3 ip = object_point_to_world<MOTION>(sc, objc, x.id, time, x.o + x.d * t);             // Sphere.cpp:128 (no identity shortcut, Q9)
@@ -340,18 +358,20 @@ struct TraceDbg { unsigned nodes, boxes, tris, sph, v[10]; };
 // Traversal stack: LDS_STACK entries per lane in LDS ([entry][thread], conflict-free), deeper entries in a global column.
 // The overflow accesses are volatile so that the compiler keeps two separate paths (ds_* and global_*) instead of one
 // FLAT access through a selected pointer, which would tie every push/pop to both memory counters.
-__device__ __forceinline__ void stack_push(int *lds_col, int *ovf_col, int ovf_stride, int sp, int v) {
+// LDS pointers are kept in their own address space: 32-bit offsets instead of 64-bit generic pointers (two VGPRs each, which the
+// register allocator spilled and reloaded on the pop path).  The overflow column is addressed as uniform base + thread index.
+__device__ __forceinline__ void stack_push(lds_int *lds_col, int *ovf, int ovf_idx, int ovf_stride, int sp, int v) {
     if (sp < LDS_STACK) lds_col[sp * TRACE_BLOCK] = v;
-    else *(volatile int *)(ovf_col + (size_t)(sp - LDS_STACK) * ovf_stride) = v;
+    else *(volatile int *)(ovf + ((size_t)(sp - LDS_STACK) * ovf_stride + ovf_idx)) = v;
 }
-__device__ __forceinline__ int stack_pop(const int *lds_col, const int *ovf_col, int ovf_stride, int sp) {
+__device__ __forceinline__ int stack_pop(const lds_int *lds_col, const int *ovf, int ovf_idx, int ovf_stride, int sp) {
     if (sp < LDS_STACK) return lds_col[sp * TRACE_BLOCK];
-    return *(const volatile int *)(ovf_col + (size_t)(sp - LDS_STACK) * ovf_stride);
+    return *(const volatile int *)(ovf + ((size_t)(sp - LDS_STACK) * ovf_stride + ovf_idx));
 }
 
 template <bool COUNT, bool MOTION, class IO>
-__device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io, int n, int *fetch_counter, int *lds_col, float *pay, const float *objc,
-                                                 int *ovf_col, int ovf_stride, TraceDbg &dbg, unsigned long long *hist) {
+__device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io, int n, int *fetch_counter, lds_int *lds_col, lds_float *pay, const lds_float *objc,
+                                                 int *ovf, int ovf_stride, TraceDbg &dbg, unsigned long long *hist) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const float4 *nodes4 = reinterpret_cast<const float4 *>(sc.nodes);
@@ -362,7 +382,8 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
     bool has_ray = false;
     float amb = 1e-6f;
     int sp = 0, cur = CUR_DONE, prim_i = 0, prim_end = 0;
-    int *payi = reinterpret_cast<int *>(pay);
+    lds_int *payi = (lds_int *)pay;
+    const int ovf_idx = blockIdx.x * TRACE_BLOCK + threadIdx.x;      // this thread's column of the overflow area
     int best_prim = -1, local_prim = -1;
     float best_t = FLT_MAX, local_t = FLT_MAX;
     f3 o = mk3(0, 0, 0), r = mk3(0, 0, 1), marg = mk3(0, 0, 0);
@@ -507,7 +528,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                         const int slot = g_sbase + irank / ngive;
                         const bool take = !has_ray && slot < g_sp;
                         int entry = 0;
-                        if (take) entry = stack_pop(lds_col + (src - lane), ovf_col + (src - lane), ovf_stride, slot);
+                        if (take) entry = stack_pop(lds_col + (src - lane), ovf, ovf_idx + (src - lane), ovf_stride, slot);
                         if (can_give) {
                             const int grank = __popcll(givers & lt_mask);
                             const int want = (nidle - grank + ngive - 1) / ngive;       // idle lanes assigned to this giver
@@ -519,7 +540,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                         const float dx = __shfl(dirx, src);
                         const float rx = __shfl(r.x, src), ry = __shfl(r.y, src), rz = __shfl(r.z, src);
                         const float mx = __shfl(marg.x, src), my = __shfl(marg.y, src), mz = __shfl(marg.z, src);
-                        const float tm = __shfl(time, src), am = __shfl(amb, src), bd = __shfl(bound, src);
+                        const float tm = MOTION ? __shfl(time, src) : 0.0f, am = __shfl(amb, src), bd = __shfl(bound, src);
                         const int en = entry;
                         if (take) {
                             o = mk3(ox, oy, oz); dirx = dx; r = mk3(rx, ry, rz); marg = mk3(mx, my, mz);
@@ -557,7 +578,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
             prim_i = start; prim_end = start + count;
             local_t = FLT_MAX; local_prim = -1;
             if (sp == sbase) cur = CUR_NONE;
-            else { --sp; cur = stack_pop(lds_col, ovf_col, ovf_stride, sp); }
+            else { --sp; cur = stack_pop(lds_col, ovf, ovf_idx, ovf_stride, sp); }
         }
 
         // ---------------- per lane and iteration: a node step AND, when the wave runs its primitive path, one primitive test ----------------
@@ -645,7 +666,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                 // for it the internal child gets the reference's exact test of its own box.
                 if (c == 2) { if (cref[i] < 0 || !(amb < 1.0f)) need_chain = true; else c = 1; }
                 cls[i] = c;
-                key[i] = fminf(fmaxf(tn, 0.0f), FLT_MAX);         // NaN -> 0
+                key[i] = fminf(fmaxf(tn, 0.0f), sc.p.flt_max);    // NaN -> 0, +inf -> FLT_MAX (+inf marks a child that is not taken)
             }
             if (COUNT) { ++dbg.nodes; dbg.boxes += 4; ++ray_steps; }
             if (any_far) {
@@ -687,14 +708,14 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                     const int i1 = npush >= 1 ? sp + npush - 1 : LDS_STACK, i2 = npush >= 2 ? sp + npush - 2 : LDS_STACK, i3 = npush >= 3 ? sp : LDS_STACK;
                     lds_col[i1 * TRACE_BLOCK] = cref[1]; lds_col[i2 * TRACE_BLOCK] = cref[2]; lds_col[i3 * TRACE_BLOCK] = cref[3];
                 } else {
-                    if (npush >= 3) stack_push(lds_col, ovf_col, ovf_stride, sp, cref[3]);
-                    if (npush >= 2) stack_push(lds_col, ovf_col, ovf_stride, sp + npush - 2, cref[2]);
-                    if (npush >= 1) stack_push(lds_col, ovf_col, ovf_stride, sp + npush - 1, cref[1]);
+                    if (npush >= 3) stack_push(lds_col, ovf, ovf_idx, ovf_stride, sp, cref[3]);
+                    if (npush >= 2) stack_push(lds_col, ovf, ovf_idx, ovf_stride, sp + npush - 2, cref[2]);
+                    if (npush >= 1) stack_push(lds_col, ovf, ovf_idx, ovf_stride, sp + npush - 1, cref[1]);
                 }
                 sp += npush;
                 cur = cref[0];
             } else if (sp == sbase) cur = CUR_NONE;
-            else { --sp; cur = stack_pop(lds_col, ovf_col, ovf_stride, sp); }
+            else { --sp; cur = stack_pop(lds_col, ovf, ovf_idx, ovf_stride, sp); }
         }
         if (has_ray && cur == CUR_NONE && !(prim_i < prim_end)) cur = CUR_DONE;
     }
@@ -782,8 +803,17 @@ __device__ __forceinline__ void flush_counters(DevCounters *counters, unsigned n
 struct RenderIO {
     enum { DBG_SET = 0 };
     LevelBuf lv;
-    int n_closest;
+    int n_closest;                 // closest-hit rays of lv; when closest_dev is set: their upper bound (the queue's capacity)
+    const int *closest_dev;        // device counter holding the real number (a level whose length the host never reads), or null
+    int shadow_cap;                // capacity of the shadow queue (its length is the device counter sb.count)
     ShadowBuf sb;
+    // called once per thread at kernel start: takes the counts from the device; returns the total queue length
+    __device__ __forceinline__ int resolve(int, const int *) {
+        if (closest_dev) { const int c = *closest_dev; n_closest = c < n_closest ? c : n_closest; }
+        int ns = 0;
+        if (shadow_cap > 0) { ns = *sb.count; ns = ns < shadow_cap ? ns : shadow_cap; }
+        return n_closest + ns;
+    }
     __device__ __forceinline__ int kind(int i) const { return i < n_closest ? 0 : 1; }
     __device__ __forceinline__ bool load(int i, f3 &o, f3 &d, float &time) const {
         const float4 *po = lv.ray_o, *pd = lv.ray_d;
@@ -812,6 +842,7 @@ struct RenderIO {
 // rt_intersect_batch: AccelerationStructure::Intersect for n independent rays (traversal, then k_finalize_batch)
 struct BatchIO {
     enum { DBG_SET = 0 };
+    __device__ __forceinline__ int resolve(int n, const int *n_dev) { return n_dev ? n + *n_dev : n; }
     __device__ __forceinline__ int kind(int) const { return 0; }
     const rt_ray *rays;
     rt_hit *hits;
@@ -844,12 +875,11 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(4))
         }
         __syncthreads();
     }
-    if (n_dev) n += *n_dev;                       // + the part of the queue whose length was produced on the device
-    const int gtid = blockIdx.x * TRACE_BLOCK + threadIdx.x;
+    n = io.resolve(n, n_dev);                     // queue lengths that were produced on the device
     TraceDbg dbg;
     dbg.nodes = dbg.boxes = dbg.tris = dbg.sph = 0;
     for (int k = 0; k < 10; ++k) dbg.v[k] = 0;
-    trace_persistent<COUNT, MOTION, IO>(sc, io, n, fetch_counter, s_stack + threadIdx.x, s_pay + threadIdx.x, s_obj, ovf + gtid, ovf_stride, dbg,
+    trace_persistent<COUNT, MOTION, IO>(sc, io, n, fetch_counter, (lds_int *)s_stack + threadIdx.x, (lds_float *)s_pay + threadIdx.x, (const lds_float *)s_obj, ovf, ovf_stride, dbg,
                                         (COUNT && counters && counters->want_hist) ? &counters->hist[0] : nullptr);
     flush_counters<COUNT>(counters, dbg.nodes, dbg.boxes, dbg.tris, dbg.sph);
     if (COUNT && counters) {
@@ -913,13 +943,14 @@ static void trace_dispatch(hipStream_t s, const DevScene &sc, IO io, int n, cons
 }
 // `fetch_counter` must point to a zeroed int that no other launch in flight uses.  n_closest rays of lv (may be 0) and the
 // shadow queue sb (its length is read on the device; `shadow_bound` >= that length sizes the launch; 0 = no shadow part).
-void rt_launch_trace(hipStream_t s, const DevScene &sc, LevelBuf lv, int n_closest, ShadowBuf sb, int shadow_bound, int *fetch_counter, int *ovf,
+void rt_launch_trace(hipStream_t s, const DevScene &sc, LevelBuf lv, int n_closest, const int *closest_dev, ShadowBuf sb, int shadow_bound, int *fetch_counter, int *ovf,
                      DevCounters *counters) {
     if (n_closest <= 0 && shadow_bound <= 0) return;
-    RenderIO io; io.lv = lv; io.n_closest = n_closest > 0 ? n_closest : 0; io.sb = sb;
-    const dim3 g(trace_blocks(io.n_closest + (shadow_bound > 0 ? shadow_bound : 0))), b(TRACE_BLOCK);
+    RenderIO io; io.lv = lv; io.n_closest = n_closest > 0 ? n_closest : 0; io.closest_dev = n_closest > 0 ? closest_dev : nullptr; io.sb = sb;
+    io.shadow_cap = shadow_bound > 0 ? shadow_bound : 0;
+    const dim3 g(trace_blocks(io.n_closest + io.shadow_cap)), b(TRACE_BLOCK);
     const int stride = rt_trace_grid_threads();
-    const int *n_dev = shadow_bound > 0 ? sb.count : nullptr;
+    const int *n_dev = nullptr;
     const bool cnt = counters != nullptr, mot = sc.p.has_motion != 0;
     if (cnt && mot) hipLaunchKernelGGL((k_trace_generic<true, true, RenderIO>), g, b, 0, s, sc, io, io.n_closest, n_dev, fetch_counter, ovf, stride, counters);
     else if (cnt) hipLaunchKernelGGL((k_trace_generic<true, false, RenderIO>), g, b, 0, s, sc, io, io.n_closest, n_dev, fetch_counter, ovf, stride, counters);
@@ -1259,11 +1290,13 @@ __device__ __forceinline__ bool replaces_all(const DevScene &sc, const DevObject
 // NTEX: the scene has normal textures; RNG: it has area lights or glossy materials (the only consumers of random numbers
 // here).  The plain instantiation carries neither code path (and not their registers: 2x the occupancy).
 template <bool NTEX, bool RNG>
-__global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, LevelBuf lv, int n, ShadowBuf sb, LevelBuf next, int depth,
+__global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, LevelBuf lv, int n, const int *n_dev, ShadowBuf sb, LevelBuf next, int depth,
                                                    int *next_count) {
     // Queue space is reserved once per 256-thread block (two atomics per block: same-address atomics from every wave cost
     // ~6 ns each, chip-wide serial).  Inactive threads of the last block take part in the barriers with lit = false, no children.
     __shared__ int s_lit[4], s_child[4], s_refl[4], s_base[2];
+    if (n_dev) { const int c = *n_dev; n = c < n ? c : n; }        // the level's length lives on the device; n is its bound
+    if ((int)(blockIdx.x * blockDim.x) >= n) return;               // whole block beyond the queue (block-uniform: before any barrier)
     const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i0 < n;
     const int i = active ? i0 : n - 1;          // inactive threads recompute the last ray and write nothing
@@ -1399,9 +1432,14 @@ __global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, L
     if (threadIdx.x == 0) {
         const int block_child = block_refr + s_refl[0] + s_refl[1] + s_refl[2] + s_refl[3];
         s_base[0] = (block_lit && nl) ? atomicAdd(sb.count, block_lit * nl) : 0;
-        s_base[1] = block_child ? atomicAdd(next_count, block_child) : 0;
+        int cb = block_child ? atomicAdd(next_count, block_child) : 0;
+        // The next level's queue was sized from an estimate: a block whose children do not fit writes none.  The counter keeps
+        // counting, so the host sees count > capacity afterwards and renders the batch again with exact sizes.
+        if (cb + block_child > next.capacity) cb = -1;
+        s_base[1] = cb;
     }
     __syncthreads();
+    if (s_base[1] < 0) { has_refr = false; has_refl = false; }
     // the block's refraction children sit together, then its reflection children (rays of one kind are the coherent ones)
     int lit_rank = __popcll(m_lit & below), slot_refr = s_base[1] + __popcll(m1 & below), slot_refl = s_base[1] + block_refr + __popcll(m2 & below);
     for (int w = 0; w < wave; ++w) { lit_rank += s_lit[w]; slot_refr += s_child[w]; slot_refl += s_refl[w]; }
@@ -1441,8 +1479,9 @@ __global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, L
 }
 // Rays per kind of a level (one "ray" = one closest-hit query), only when the caller asked for rt_stats: the shadow rays and
 // the children this level spawned, from the child table (block reduction, one atomic per block and kind).
-__global__ __launch_bounds__(256) void k_count_kinds(LevelBuf lv, int n, const int *shadow_count, unsigned long long *kind_counts) {
+__global__ __launch_bounds__(256) void k_count_kinds(LevelBuf lv, int n, const int *n_dev, const int *shadow_count, unsigned long long *kind_counts) {
     __shared__ unsigned s_r[4], s_t[4];
+    if (n_dev) { const int c = *n_dev; n = c < n ? c : n; }
     unsigned r = 0, t = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int2 ch = lv.child[i];
@@ -1458,27 +1497,28 @@ __global__ __launch_bounds__(256) void k_count_kinds(LevelBuf lv, int n, const i
         if (blockIdx.x == 0 && shadow_count) atomicAdd(&kind_counts[RT_RAY_SHADOW], (unsigned long long)*shadow_count);
     }
 }
-void rt_launch_shade_pre(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, ShadowBuf sb, LevelBuf next, int depth,
+void rt_launch_shade_pre(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, const int *n_dev, ShadowBuf sb, LevelBuf next, int depth,
                          int *next_count) {
     if (n <= 0) return;
     const dim3 g((n + 255) / 256), b(256);
     const bool ntex = sc.p.has_normal_tex != 0, rng = sc.p.has_rng != 0;
-    if (ntex && rng) hipLaunchKernelGGL((k_shade_pre<true, true>), g, b, 0, s, sc, cam, lv, n, sb, next, depth, next_count);
-    else if (ntex) hipLaunchKernelGGL((k_shade_pre<true, false>), g, b, 0, s, sc, cam, lv, n, sb, next, depth, next_count);
-    else if (rng) hipLaunchKernelGGL((k_shade_pre<false, true>), g, b, 0, s, sc, cam, lv, n, sb, next, depth, next_count);
-    else hipLaunchKernelGGL((k_shade_pre<false, false>), g, b, 0, s, sc, cam, lv, n, sb, next, depth, next_count);
+    if (ntex && rng) hipLaunchKernelGGL((k_shade_pre<true, true>), g, b, 0, s, sc, cam, lv, n, n_dev, sb, next, depth, next_count);
+    else if (ntex) hipLaunchKernelGGL((k_shade_pre<true, false>), g, b, 0, s, sc, cam, lv, n, n_dev, sb, next, depth, next_count);
+    else if (rng) hipLaunchKernelGGL((k_shade_pre<false, true>), g, b, 0, s, sc, cam, lv, n, n_dev, sb, next, depth, next_count);
+    else hipLaunchKernelGGL((k_shade_pre<false, false>), g, b, 0, s, sc, cam, lv, n, n_dev, sb, next, depth, next_count);
 }
 // rays per kind of a level after its surface pass (statistics only; a launch of its own so that the host can queue it behind
 // the copy of the child count)
-void rt_launch_count_kinds(hipStream_t s, LevelBuf lv, int n, ShadowBuf sb, unsigned long long *kind_counts) {
+void rt_launch_count_kinds(hipStream_t s, LevelBuf lv, int n, const int *n_dev, ShadowBuf sb, unsigned long long *kind_counts) {
     if (n <= 0 || !kind_counts) return;
-    hipLaunchKernelGGL(k_count_kinds, dim3(std::min((n + 255) / 256, 512)), dim3(256), 0, s, lv, n, sb.count, kind_counts);
+    hipLaunchKernelGGL(k_count_kinds, dim3(std::min((n + 255) / 256, 512)), dim3(256), 0, s, lv, n, n_dev, sb.count, kind_counts);
 }
 
 // After the shadow rays of the level are traced: the local colour of every hit (ProcessLights, LightContributionCalculator.cpp:98-124),
 // the background for misses, the texture for replace_all decals.
-__global__ __launch_bounds__(256) void k_shade_post(DevScene sc, DevCamera cam, LevelBuf lv, int n, ShadowBuf sb) {
+__global__ __launch_bounds__(256) void k_shade_post(DevScene sc, DevCamera cam, LevelBuf lv, int n, const int *n_dev, ShadowBuf sb) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) { const int c = *n_dev; n = c < n ? c : n; }
     if (i >= n) return;
     float t;
     const Surf s = load_surf(lv, i, t);
@@ -1519,14 +1559,15 @@ __global__ __launch_bounds__(256) void k_shade_post(DevScene sc, DevCamera cam, 
     a.x = L.x; a.y = L.y; a.z = L.z;
     lv.node_a[i] = a;
 }
-void rt_launch_shade_post(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, ShadowBuf sb) {
+void rt_launch_shade_post(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, const int *n_dev, ShadowBuf sb) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_shade_post, dim3((n + 255) / 256), dim3(256), 0, s, sc, cam, lv, n, sb);
+    hipLaunchKernelGGL(k_shade_post, dim3((n + 255) / 256), dim3(256), 0, s, sc, cam, lv, n, n_dev, sb);
 }
 
 // Backward sweep: colour(ray) = local + children, in the association order of RecursiveComputation.cpp:62-69,130-141,172-173.
-__global__ __launch_bounds__(256) void k_backward(LevelBuf lv, int n, LevelBuf next, int has_next) {
+__global__ __launch_bounds__(256) void k_backward(LevelBuf lv, int n, const int *n_dev, LevelBuf next, int has_next) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) { const int c = *n_dev; n = c < n ? c : n; }
     if (i >= n) return;
     const float4 a = lv.node_a[i];
     const int flags = __float_as_int(a.w);
@@ -1548,9 +1589,9 @@ __global__ __launch_bounds__(256) void k_backward(LevelBuf lv, int n, LevelBuf n
     }
     lv.color[i] = make_float4(C.x, C.y, C.z, (flags & NODE_HIT) ? 1.0f : 0.0f);
 }
-void rt_launch_backward(hipStream_t s, LevelBuf lv, int n, LevelBuf next, int has_next) {
+void rt_launch_backward(hipStream_t s, LevelBuf lv, int n, const int *n_dev, LevelBuf next, int has_next) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_backward, dim3((n + 255) / 256), dim3(256), 0, s, lv, n, next, has_next);
+    hipLaunchKernelGGL(k_backward, dim3((n + 255) / 256), dim3(256), 0, s, lv, n, n_dev, next, has_next);
 }
 
 // RenderMultiSampled's mean (DefaultRenderer.cpp:111-122) / RenderWithOneSample; also the primary hit id of sample 0.

@@ -75,19 +75,23 @@ struct DevCounters {        // accumulated with atomics when counting is enabled
 
 void rt_launch_raygen(hipStream_t s, const DevCamera &cam, const int *pixel_list, int first_pixel, int n_samples, LevelBuf lv);
 // fetch_counter: a zeroed int in device memory, private to the launch (the persistent waves draw ray indices from it).
-// One launch traces lv's n_closest rays and the shadow queue sb (length on the device, at most shadow_bound; 0 = none).
-void rt_launch_trace(hipStream_t s, const DevScene &sc, LevelBuf lv, int n_closest, ShadowBuf sb, int shadow_bound, int *fetch_counter,
+// One launch traces lv's closest-hit rays and the shadow queue sb (length on the device, at most shadow_bound; 0 = none).
+// Queue lengths: every launcher takes (n, n_dev).  n_dev == nullptr: the queue holds n entries.  Otherwise the real length is
+// the device counter *n_dev (a level whose size the host never reads back) and n is its upper bound = the capacity the
+// queue was allocated with; the kernels use min(*n_dev, n) and the grid is sized for n.
+void rt_launch_trace(hipStream_t s, const DevScene &sc, LevelBuf lv, int n_closest, const int *closest_dev, ShadowBuf sb, int shadow_bound, int *fetch_counter,
                      int *overflow_stack, DevCounters *counters);
 void rt_launch_trace_batch(hipStream_t s, const DevScene &sc, const rt_ray *rays, rt_hit *hits, int n, int *fetch_counter, int *overflow_stack, DevCounters *counters,
                            int max_blocks = 0, int ovf_stride = 0);
 void rt_launch_fill_int(hipStream_t s, int *p, int n, int v);   // p[0..n) = v, as a kernel
 int rt_trace_block_threads();    // threads per block of the trace kernels
 int rt_trace_resident_blocks();  // blocks of the trace kernels resident on the device at a time (the grid cap)
-void rt_launch_shade_pre(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, ShadowBuf sb, LevelBuf next, int depth,
+// next.capacity bounds the children written: a block whose children do not fit writes none, *next_count still counts them
+void rt_launch_shade_pre(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, const int *n_dev, ShadowBuf sb, LevelBuf next, int depth,
                          int *next_count);
-void rt_launch_count_kinds(hipStream_t s, LevelBuf lv, int n, ShadowBuf sb, unsigned long long *ray_kind_counts);
-void rt_launch_shade_post(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, ShadowBuf sb);
-void rt_launch_backward(hipStream_t s, LevelBuf lv, int n, LevelBuf next, int has_next);
+void rt_launch_count_kinds(hipStream_t s, LevelBuf lv, int n, const int *n_dev, ShadowBuf sb, unsigned long long *ray_kind_counts);
+void rt_launch_shade_post(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, const int *n_dev, ShadowBuf sb);
+void rt_launch_backward(hipStream_t s, LevelBuf lv, int n, const int *n_dev, LevelBuf next, int has_next);
 void rt_launch_resolve(hipStream_t s, const DevCamera &cam, const int *pixel_list, int first_pixel, int n_pixels, LevelBuf lv0, int compact,
                        float *hdr, int *prim_id, float *prim_t);
 void rt_set_trace_block_cap(int cap);   // experiment hook: upper bound of the persistent grid (0 = default)

@@ -164,3 +164,37 @@ def test_renderer_with_tonemap_writes_exr(rt, orc, scene_path, tmp_path):
     ok = ~np.isnan(want)
     assert params[1] == wparams[1] and np.allclose(mapped[ok], want[ok], rtol=1e-3, atol=1e-6)
     r.close()
+
+
+def test_frames_after_the_first_make_no_host_round_trip(rt, orc, gpu_ctx, scene_path):
+    """The first frame of a scene reads every level's child count on the host; later frames size queues and launches from the
+    previous frame's counts, keep the level lengths on the device (rt_stats.level_syncs == 0) and give the same frame bit for
+    bit.  A frame that outgrows the prediction (here: the camera turns from the sky to the mirrors) is rendered a second time
+    with host counts (frame_passes == 2) and is still exact."""
+    soup = rt.SceneSoup.load(scene_path("cornellbox_recursive"))
+    gpu_ctx.upload(soup)
+    h1, i1, t1, s1 = gpu_ctx.render(0, nx=200, ny=200, timing=1)
+    assert s1.level_syncs > 0 and s1.frame_passes == 1
+    h2, i2, t2, s2 = gpu_ctx.render(0, nx=200, ny=200, timing=1)
+    assert s2.level_syncs == 0 and s2.frame_passes == 1
+    assert np.array_equal(h1.view(np.uint32), h2.view(np.uint32)) and np.array_equal(i1, i2) and np.array_equal(t1.view(np.uint32), t2.view(np.uint32))
+    assert list(s1.rays) == list(s2.rays) and s1.trace_rays == s2.trace_rays
+    # several batches per frame on two streams, still without a round trip
+    h3, i3, _, s3 = gpu_ctx.render(0, nx=200, ny=200, max_batch_samples=6000, num_streams=2)
+    assert s3.level_syncs == 0 and s3.frame_passes == 1 and np.array_equal(h3.view(np.uint32), h1.view(np.uint32))
+    # a camera that sees nothing: almost no secondary rays ...
+    cd = soup.camera_desc(0, nx=200, ny=200)
+    away = type(cd).from_buffer_copy(cd)
+    away.gaze[0], away.gaze[1], away.gaze[2] = 0.0, 0.0, 1.0
+    h4, i4, _, s4 = gpu_ctx.render(away)
+    assert (i4 == -1).all() and s4.frame_passes == 1
+    # ... then back to the box: every level outgrows the prediction -> second pass, same frame as before
+    h5, i5, t5, s5 = gpu_ctx.render(0, nx=200, ny=200)
+    assert s5.frame_passes == 2 and s5.level_syncs > 0
+    assert np.array_equal(h5.view(np.uint32), h1.view(np.uint32)) and np.array_equal(i5, i1)
+    assert list(s5.rays) == list(s1.rays)
+    h6, _, _, s6 = gpu_ctx.render(0, nx=200, ny=200)
+    assert s6.level_syncs == 0 and s6.frame_passes == 1 and np.array_equal(h6.view(np.uint32), h1.view(np.uint32))
+    c_hdr, c_id, c_t, c_st = orc.OracleScene(soup).render(0, nthreads=8, nx=200, ny=200)
+    compare_frames(h6, c_hdr, i1, c_id, t1, c_t)
+    assert list(s6.rays) == list(c_st.rays)
