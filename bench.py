@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--tris", type=int, default=1_000_000, help="triangles of the stand-in mesh (config 2: 1M)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: the resolution grows with N (each GPU keeps config 2's 800x480 share); strong: one fixed frame (800x480 at --spp samples) cut over the N GPUs")
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel (default: 1 = config 2 as quoted; 16 with --scaling strong)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-step", type=int, default=1, help="CPU baseline renders every k-th row of the frame")
     args = ap.parse_args()
@@ -71,8 +74,12 @@ def main():
     synth = importlib.import_module("ray-tracer_amd.synth")
     abi = rt.abi
 
-    nx, ny = resolution_for(world)
+    strong = args.scaling == "strong"
+    spp = args.spp if args.spp > 0 else (16 if strong else 1)
+    nx, ny = resolution_for(1 if strong else world)
     soup = synth.dragon_standin_scene(args.tris, nx, ny)
+    if spp != 1:
+        soup.cameras[0]["num_samples"] = spp
     ctx = rt.Context(local_rank)
     t0 = time.time()
     ctx.upload(soup)
@@ -139,11 +146,16 @@ def main():
     bytes_per_launch = frame_bytes / launches
     avg_launch_ms = trace_ms / launches
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC passes (tools/pmc_passes.sh + tools/traffic_json.py): only quoted when they were taken with
+    # exactly this library (the file records its SHA-256) and for this workload; otherwise null
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and world == 1 and spp == 1 and args.tris == 1_000_000:
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_trace_launch")
+            import hashlib
+            tj = json.load(open(tpath))
+            if tj.get("lib_sha256") == hashlib.sha256(open(rt.renderer.LIB_PATH, "rb").read()).hexdigest():
+                traffic = tj.get("hbm_bytes_per_trace_launch")
         except Exception:
             traffic = None
     # the same launch time priced with SURVEY 8(d)'s own yardstick: 64 B per node visit and per primitive test of a canonical
@@ -151,7 +163,7 @@ def main():
     survey = None
     cpath = os.path.join(ROOT, "tests", "golden", "canonical_counts.json")
     ckey = "config2 dragon_standin_%d %dx%d" % (args.tris, nx, ny)
-    if os.path.exists(cpath):
+    if os.path.exists(cpath) and spp == 1:
         try:
             cc = json.load(open(cpath)).get(ckey)
             if cc and cc["rays"] == int(n_rays) and world == 1:
@@ -177,11 +189,17 @@ def main():
     if not args.no_cpu_baseline and world == 1:       # rank 0 at N=1 only
         from oracle import orc
         osc = orc.OracleScene(soup)
-        cores = min(16, os.cpu_count() or 1)
+        # one thread per core this job may use: the affinity mask, capped by OMP_NUM_THREADS (the GPU box grants 16 of the
+        # machine's cores to a one-GPU job); os.cpu_count() — the whole machine — is reported next to it
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        cores = max(1, min(avail, int(os.environ.get("OMP_NUM_THREADS", avail) or avail)))
         t0 = time.perf_counter()
         _, _, _, cst = osc.render(0, nthreads=cores, dynamic=True, row_step=args.cpu_row_step, want_ids=False)
         cpu_s = time.perf_counter() - t0
-        cpu = {"value": round(sum(cst.rays) / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+        cpu = {"value": round(sum(cst.rays) / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": "port",
                "sample": "every %dth row of the %dx%d frame (%d rows, %d rays, %.1f s), oracle/rt_oracle.cpp with %d threads, rows handed out dynamically"
                          % (args.cpu_row_step, nx, ny, len(range(0, ny, args.cpu_row_step)), sum(cst.rays), cpu_s, cores)}
         # the reference's own split (DefaultRenderer.cpp:65-75): 8 threads, static row bands
@@ -190,14 +208,29 @@ def main():
         cpu["value_8_static_bands"] = round(sum(cst8.rays) / (time.perf_counter() - t0) / 1e6, 4)
         osc.close()
 
+    # the share one GPU of eight gets of this frame (every 8th 32x32 tile): what fixed costs leave of strong scaling
+    share_ms = None
+    if world == 1:
+        o8 = ctx.make_opts(seed=0, tile_size=TILE, tile_rank=0, tile_world=8, output_on_device=True, compact_output=True, timing=1)
+        for _ in range(3):
+            ctx.render_device(cd, o8, tg.tile_hdr.data_ptr(), None, None, abi.Stats())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            st8 = ctx.render_device(cd, o8, tg.tile_hdr.data_ptr(), None, None, abi.Stats())
+        torch.cuda.synchronize()
+        share_ms = {"ms_per_frame": round((time.perf_counter() - t0) * 100.0, 4), "kernels_ms": round(st8.ms_kernels, 4), "rays": int(sum(st8.rays)),
+                    "level_syncs": int(st8.level_syncs)}
     bvh = ctx.bvh_info()
     out = {"metric": "Mrays/s (primary+secondary, whole node)", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "BASELINE config 2: other_dragon.xml camera/lights/materials, depth 6, 1 spp, stand-in %d-triangle mesh "
-                                  "(dragon_remeshed.ply is a missing blob) + mirror floor" % args.tris,
-                      "resolution": [nx, ny], "spp": 1, "rays_per_frame": int(total_rays), "tiles": "%dx%d interleaved over %d GPU(s)" % (TILE, TILE, world),
-                      "bvh_nodes": int(bvh.n_nodes), "bvh_depth": int(bvh.max_depth), "scene_upload_s": round(upload_s, 2), "kernels_ms_per_frame": round(sum(s.ms_kernels for s in st_steps) / args.steps, 4)},
+           "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "BASELINE config 2: other_dragon.xml camera/lights/materials, depth 6, %d spp, stand-in %d-triangle mesh "
+                                  "(dragon_remeshed.ply is a missing blob) + mirror floor" % (spp, args.tris),
+                      "resolution": [nx, ny], "spp": spp, "rays_per_frame": int(total_rays), "tiles": "%dx%d interleaved over %d GPU(s)" % (TILE, TILE, world),
+                      "bvh_nodes": int(bvh.n_nodes), "bvh_depth": int(bvh.max_depth), "scene_upload_s": round(upload_s, 2), "kernels_ms_per_frame": round(sum(s.ms_kernels for s in st_steps) / args.steps, 4),
+                      "host_round_trips_per_frame": int(st_steps[-1].level_syncs), "traversal": "exact (normal-cone pruning rule): hit ids equal the reference's unpruned traversal",
+                      "one_gpu_of_eight_share": share_ms},
            "roofline": roofline, "cpu_baseline": cpu}
     print(json.dumps(out))
     if world > 1:

@@ -13,9 +13,13 @@ from . import renderer
 class TileGather:
     """Pre-computes the tile ownership of a frame and gathers / de-interleaves compact tile buffers on rank 0."""
 
-    def __init__(self, nx, ny, tile_size, rank, world, device, torch):
+    def __init__(self, nx, ny, tile_size, rank, world, device, torch, host_staging=False):
+        """host_staging: the process group cannot take device tensors (gloo): the tiles rendered into HBM are copied to host
+        memory with a synchronous copy, gathered there, and the frame is assembled on the host (a rehearsal path for boxes
+        where several ranks share one GPU; production uses the nccl backend = RCCL over xGMI on device tensors)."""
         self.nx, self.ny, self.tile, self.rank, self.world = nx, ny, tile_size, rank, world
         self.torch = torch
+        self.host_staging = bool(host_staging)
         L = renderer.library()
         self.counts = [int(L.rt_owned_pixel_count(nx, ny, tile_size, r, world)) for r in range(world)]
         self.max_owned = max(self.counts)
@@ -26,11 +30,12 @@ class TileGather:
         self.events = [None, None]
         self.cur = 0
         self.tile_hdr = self.buffers[0]
-        self.gathered = torch.zeros((world, self.max_owned, 3), dtype=torch.float32, device=device) if (world > 1 and rank == 0) else None
-        self.frame = torch.zeros((ny * nx, 3), dtype=torch.float32, device=device) if rank == 0 else None
+        gdev = torch.device("cpu") if self.host_staging else device
+        self.gathered = torch.zeros((world, self.max_owned, 3), dtype=torch.float32, device=gdev) if (world > 1 and rank == 0) else None
+        self.frame = torch.zeros((ny * nx, 3), dtype=torch.float32, device=gdev) if rank == 0 else None
         self.orders = None
         if rank == 0:
-            self.orders = [torch.from_numpy(renderer.tile_pixel_order(nx, ny, tile_size, r, world).astype(np.int64)).to(device)
+            self.orders = [torch.from_numpy(renderer.tile_pixel_order(nx, ny, tile_size, r, world).astype(np.int64)).to(gdev)
                            for r in range(world)]
 
     def acquire(self):
@@ -53,11 +58,12 @@ class TileGather:
                 self.events[self.cur] = ev
 
     def _gather(self, dist=None):
+        src = self.tile_hdr.cpu() if self.host_staging else self.tile_hdr        # .cpu(): synchronous device-to-host copy
         if self.world > 1:
-            dist.gather(self.tile_hdr, list(self.gathered.unbind(0)) if self.rank == 0 else None, dst=0)
+            dist.gather(src, list(self.gathered.unbind(0)) if self.rank == 0 else None, dst=0)
             if self.rank == 0:
                 for r in range(self.world):
                     self.frame.index_copy_(0, self.orders[r], self.gathered[r, :self.counts[r]])
         elif self.rank == 0:
-            self.frame.index_copy_(0, self.orders[0], self.tile_hdr[:self.counts[0]])
+            self.frame.index_copy_(0, self.orders[0], src[:self.counts[0]])
         return self.frame
