@@ -92,7 +92,7 @@ def main():
     def step(opts, stats):
         tg.acquire()                                                              # the other of two tile buffers: frame i's gather may still run
         ctx.render_device(cd, opts, tg.tile_hdr.data_ptr(), None, None, stats)    # returns after the stream is idle
-        # the only exchange step of the path: HDR tiles -> rank 0 (SURVEY §8e); point-to-point gather over xGMI
+        # the only exchange step of the path: HDR tiles -> rank 0; point-to-point gather over xGMI
         tg.gather(dist)
 
     def sync():
@@ -158,7 +158,7 @@ def main():
                 traffic = tj.get("hbm_bytes_per_trace_launch")
         except Exception:
             traffic = None
-    # the same launch time priced with SURVEY 8(d)'s own yardstick: 64 B per node visit and per primitive test of a canonical
+    # the same launch time priced with a second, traversal-independent yardstick: 64 B per node visit and per primitive test of a canonical
     # binary, nearest-first, pruned traversal of the reference tree (counted by the CPU oracle, tests/golden/canonical_counts.json)
     survey = None
     cpath = os.path.join(ROOT, "tests", "golden", "canonical_counts.json")
@@ -171,7 +171,7 @@ def main():
                 survey = {"bytes_per_ray": round(cc["bytes_per_ray"], 1), "nodes_per_ray": round(cc["nodes"] / cc["rays"], 2),
                           "tris_per_ray": round(cc["tris"] / cc["rays"], 2), "achieved": round(sbytes / (avg_launch_ms * 1e-3) / 1e9, 2),
                           "frac": round(sbytes / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
-                # SURVEY 8(d)'s flop count of the same canonical traversal (24 per node visit, 140 per triangle, 60 per sphere test)
+                # flop count of the same canonical traversal (24 per node visit, 140 per triangle, 60 per sphere test)
                 # against the FP32 vector peak it names (157 TFLOP/s): the path is nowhere near a compute roofline
                 sflops = 24.0 * cc["nodes"] + 140.0 * cc["tris"] + 60.0 * cc["spheres"]
                 survey["flops_per_ray"] = round(sflops / cc["rays"], 1)

@@ -287,7 +287,7 @@ int rt_perlin_tables(int n_tables, int32_t *out);
 /* ObtainColorFromUnclampedVector (src/DefaultRenderer.cpp:18-27): float RGB -> 8-bit, n = pixel count. */
 int rt_resolve_8bit(const float *hdr_rgb, int64_t n_pixels, uint8_t *out_rgb);
 
-/* ---- what the reference does with the finished frame, on the device ---------------------- */
+/* ---- what the reference does with the finished frame (8-bit image, PPM / EXR file, tone mapper), on the device ---------------------- */
 
 enum { RT_IMG_RGB8 = 0,      /* the reference's Image contents: ny*nx*3 unsigned chars                            */
        RT_IMG_PPM_P3 = 1,    /* the file Image::SaveImageAsPPM writes, byte for byte                                */

@@ -3,7 +3,7 @@
 // The reference's host is C++ (src/main.cpp:15-30: parse a scene, `new DefaultRenderer()`, RenderSceneIntoPPM, delete), so
 // this is the same shape in the same language: two classes with the names and call signatures of the reference's plugin
 // interfaces, working on a flattened scene (SceneView: the content of the reference's `Scene` after parsing) instead of the
-// reference's own class graph, which cannot be linked here (INTEGRATION.md shows the subclass a maintainer adds on top).
+// reference's own class graph, which cannot be linked here (a maintainer adds the same two subclasses on top of the reference's headers).
 //
 //   rt_mi355::Mi355Renderer      <->  RenderStrategy        (src/RenderStrategy.h:12-26, DefaultRenderer.cpp:35-162)
 //   rt_mi355::Mi355Accelerator   <->  AccelerationStructure (src/AccelerationStructure.h:12-26, BVHTree.cpp:155-206)

@@ -101,7 +101,7 @@ class OracleScene:
         return hdr, pid, pt, st
 
     def canonical_counts(self, cam=0, seed=0, nthreads=8, **cam_override):
-        """SURVEY 8d: {rays, nodes, tris, spheres} of the frame's rays through the canonical pruned traversal."""
+        """{rays, nodes, tris, spheres} of the frame's rays through the canonical pruned traversal."""
         cd = self.soup.camera_desc(cam, **cam_override) if not isinstance(cam, abi.CameraDesc) else cam
         out = np.zeros(4, np.uint64)
         rc = lib().orc_canonical_counts(self.h, C.byref(cd), seed, nthreads, out.ctypes.data)

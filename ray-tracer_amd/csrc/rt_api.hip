@@ -248,6 +248,12 @@ int rt_ctx_create(int hip_device_id, rt_ctx **out) {
     if (hip_device_id < 0 || hip_device_id >= n) { g_create_error = "hip_device_id out of range"; return RT_ERR_INVALID; }
     e = hipSetDevice(hip_device_id);
     if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return RT_ERR_HIP; }
+    {
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, hip_device_id);
+        if (e != hipSuccess) { g_create_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e); return RT_ERR_HIP; }
+        rt_set_num_cus(prop.multiProcessorCount);
+    }
     if (hip_device_id < RT_MAX_DEVICES && !g_noalloc_scratch[hip_device_id]) {     // once per device, with that device current
         int *ptr = nullptr;
         e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
@@ -435,7 +441,7 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
     const int max_depth = std::max(0, c->dev.p.max_depth);
     const int nl = c->dev.p.n_lights;
 
-    // owned pixels (interleaved tiles)
+    // owned pixels (interleaved tiles: tile id % tile_world == tile_rank)
     const int64_t n_owned = rt_owned_pixel_count(cam->nx, cam->ny, opts->tile_size, opts->tile_rank, opts->tile_world);
     // the pixel order only depends on (nx, ny, tile parameters): keep the device copy between frames
     const int pix_key[5] = {cam->nx, cam->ny, opts->tile_size, opts->tile_rank, opts->tile_world};

@@ -377,7 +377,7 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
                 lf.start = (int32_t)hs.prims.size();
                 for (int i = bn[n].start; i < bn[n].end; ++i) {
                     const DevPrim &rec = shapeRec[pshape[order[i]]];
-                    bool dup = false;      // a second reference to the same shape inside one leaf can never win
+                    bool dup = false;      // a second reference to the same shape inside one leaf can never win: same t, and the leaf rule needs t < best - 0.001
                     for (size_t k = lf.start; k < hs.prims.size() && !dup; ++k) dup = hs.prims[k].shape == rec.shape;
                     if (!dup) hs.prims.push_back(rec);
                 }
@@ -488,7 +488,7 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
         for (int k = 0; k < 3; ++k) scale = std::max(scale, std::max(std::fabs(hs.params.root_min[k]), std::fabs(hs.params.root_max[k])));
     hs.scene_scale = scale;
     hs.params.prune_rel = 2e-4f;
-    hs.params.prune_err = (4.0f * d->isect_eps + 2e-4f) * scale;   // eps*edge slack of the Cramer test + float error (DESIGN.md §4)
+    hs.params.prune_err = (4.0f * d->isect_eps + 2e-4f) * scale;   // eps*edge slack of the Cramer test + float error
     hs.info.n_nodes = (int64_t)bn.size(); hs.info.n_leaves = (int64_t)hs.leaves.size(); hs.info.max_depth = maxDepth; hs.info.n_wide_nodes = (int32_t)hs.nodes.size();
     hs.info.n_leaf_prims = (int64_t)hs.prims.size();
     if (device_done) {

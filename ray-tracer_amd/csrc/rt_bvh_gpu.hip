@@ -1,6 +1,6 @@
 // rt_bvh_gpu.hip — the reference's BVH build (BVHTree.cpp:39-153: top-down, 4-bin SAH on the widest centroid axis,
 // std::partition) executed level by level on the GPU, with the SAME topology, primitive order and boxes as the host
-// builder in rt_build.hip ("GPU BVH build replacing host BuildTree").
+// builder in rt_build.hip.
 //
 // Why the result is identical and not merely equivalent:
 //   * every per-node quantity is a min / max / count over the node's primitives (order independent) followed by the
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void k_mark_leaves(Tree t, int n_nodes, int *f
     const int nd = blockIdx.x * blockDim.x + threadIdx.x;
     if (nd < n_nodes && t.left[nd] < 0) flag[t.start[nd]] = 1;
 }
-// per leaf: number of distinct shapes (a second reference to a shape inside one leaf can never win)
+// per leaf: number of distinct shapes (a second reference to a shape inside one leaf can never win: same t, and the leaf rule needs t < best - 0.001)
 __global__ __launch_bounds__(256) void k_leaf_unique(Tree t, int n_nodes, const int *order, const int *pshape, const int *leaf_at, int *uniq) {
     const int nd = blockIdx.x * blockDim.x + threadIdx.x;
     if (nd >= n_nodes || t.left[nd] >= 0) return;

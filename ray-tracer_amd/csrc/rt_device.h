@@ -5,7 +5,7 @@
 //               nodes, opened greedily by surface area).  128 bytes, boxes as structure-of-arrays so that one lane
 //               tests the four child boxes with the same instruction stream.  Skipping the intermediate binary nodes is
 //               exact: boxes nest, and a leaf whose own box test is unambiguous provably passes every ancestor's test
-//               (DESIGN.md §4); only a leaf whose test is ambiguous walks DevChain[] with the reference's exact test.
+//               (boxes nest, the slab formula is monotonic); only a leaf whose test is ambiguous walks DevChain[] with the reference's exact test.
 //   DevChain  — one record per reference node (box + parent), for that rare walk.
 //   DevPrim   — one per leaf primitive reference, stored in leaf order (a leaf is a contiguous run), 64 bytes.
 // Leaves are not nodes: a child reference < 0 is ~(count << 26 | start), the leaf's run inside DevPrim[] (count = 0: the
@@ -79,7 +79,7 @@ static_assert(sizeof(DevVertex) == 32, "DevVertex must be 32 bytes");
 
 #define RT_TRI_MIN_LANES 16      // run the primitive path of the traversal once this many lanes of a wave wait in a leaf
 #define RT_DONATE_MIN_IDLE 32    // once the queue is empty: split the rays in flight (donation) when this many lanes of a wave are idle (28-36 measured best)
-#define RT_REFILL_MIN_IDLE 16    // retire + refill (or donate) once this many lanes of a wave are idle (sweeps in DESIGN.md §5)
+#define RT_REFILL_MIN_IDLE 16    // retire + refill (or donate) once this many lanes of a wave are idle (8 ... 48 swept: 16 best)
 
 struct DevSceneParams {
     int32_t max_depth;
@@ -90,7 +90,7 @@ struct DevSceneParams {
     int32_t n_lights, n_materials, n_textures;
     int32_t root;             // >= 0 DevNode4 index, < 0 leaf reference, RT_NO_ROOT when the scene is empty
     float root_min[3], root_max[3];
-    float prune_err;          // absolute bound used to keep t-pruning conservative
+    float prune_err;          // absolute bound used to keep t-pruning conservative: how far a computed hit point may lie outside its primitive's box
     float prune_rel;          // the same per unit of |origin|_1
     int32_t bvh_depth;        // depth of the reference (binary) tree
     int32_t stack_bound;      // most entries a traversal of the 4-wide tree can have on its stack

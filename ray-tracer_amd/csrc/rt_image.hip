@@ -1,4 +1,4 @@
-// rt_image.hip — what the reference does with a finished frame, on the device (SURVEY §8f rows 2 and 4):
+// rt_image.hip — what the reference does with a finished frame, on the device:
 //   * ObtainColorFromUnclampedVector (reference src/DefaultRenderer.cpp:18-27): float radiance -> 8-bit Color
 //   * Image::SaveImageAsPPM (src/Image.cpp:54-77): the P3 text, byte for byte what the fprintf loop produces
 //   * DefaultTonemapStrategy (src/DefaultTonemapStrategy.cpp:15-114): photographic tone mapping of the frame

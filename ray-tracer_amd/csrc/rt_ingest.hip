@@ -1,4 +1,4 @@
-// rt_ingest.hip — scene ingest on the device (SURVEY §8f row 3): what the reference computes in its shape constructors,
+// rt_ingest.hip — scene ingest on the device: what the reference computes in its shape constructors,
 // for scenes large enough to be built on the GPU.  The raw description arrays (positions, indices, object ids, primitive
 // list) are uploaded once; everything derived from them is produced here and stays in HBM:
 //   Triangle::Triangle            src/Triangle.cpp:48-76   edges, face normal                         k_tri_setup

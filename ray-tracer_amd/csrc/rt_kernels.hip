@@ -22,11 +22,13 @@
 
 #define TRACE_BLOCK 256
 #define LDS_STACK 20
-#define TRACE_BLOCKS_PER_CU 6        // sizes the stack-overflow area (upper bound of the grid)
 #define TRACE_RESIDENT_PER_CU 4      // blocks of the traversal kernel a CU holds (128 VGPRs, 39 KB LDS each of the 160 KB)
-#define NUM_CUS 256
 
-int rt_trace_grid_threads() { return NUM_CUS * TRACE_BLOCKS_PER_CU * TRACE_BLOCK; }
+// compute units of the device the library runs on (hipDeviceProp_t::multiProcessorCount, set by rt_ctx_create; 256 on MI355X):
+// sizes the persistent grid of the traversal and its stack-overflow area
+static int g_num_cus = 256;
+void rt_set_num_cus(int n) { if (n > 0) g_num_cus = n; }
+int rt_trace_grid_threads() { return g_num_cus * TRACE_RESIDENT_PER_CU * TRACE_BLOCK; }
 int rt_trace_lds_stack_depth() { return LDS_STACK; }
 
 // ====================================================================================================
@@ -301,7 +303,7 @@ __device__ __forceinline__ int slab_cross(float bminx, float bminy, float bminz,
 // for the leaf's box and for every ancestor's (BVHTree.cpp:160-206).  Only called for leaves whose own fast test was
 // undecided (a ray grazing the leaf box within 1e-6 relative — every hit on a flat, axis-aligned leaf box is one — or a ray
 // with a zero direction component).  Walks up: an undecided box gets the exact test; the first box the fast test decides
-// ends the walk, because a decided hit implies that every box above it passes too (nesting).
+// ends the walk, because a decided hit implies that every box above it passes too (boxes nest and every step of the slab formula is monotonic).
 __device__ __noinline__ bool chain_visit(const DevChain *chain, int node, bool leaf, f3 o, f3 d, f3 r, float amb) {
     if (!leaf) {                      // internal child of a zero-component ray: the reference's test of that one box
         const DevChain c = chain[node];
@@ -331,7 +333,7 @@ __device__ __noinline__ bool chain_visit(const DevChain *chain, int node, bool l
 // one primitive test of its pending leaf.  Both records are requested at the top of the iteration, the primitive record
 // first, so an iteration costs one memory round trip and the primitive test runs while the node record is in flight —
 // provided nothing in between waits for ALL outstanding loads (spill reloads, FLAT loads, a hoisted use of the primitive
-// record: see DESIGN.md section 4).  The expensive primitive path only runs when at least tri_min_lanes lanes hold a pending
+// record).  The expensive primitive path only runs when at least tri_min_lanes lanes hold a pending
 // leaf (or no lane has a node left); retiring and refilling is batched the same way (refill_min_idle).
 //
 // Registers: the hit payload that is only needed at the end (ip, beta, gamma of the leaf-local and of the best candidate)
@@ -569,7 +571,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
         // A lane that arrived at a leaf (root, descent or pop) unpacks its primitive run (no memory round trip of its own),
         // keeps it as its PENDING leaf and goes on with the next node from its stack: the primitive path is expensive and
         // runs only when enough lanes of the wave hold a pending leaf, and meanwhile the lane does not idle.  Visiting
-        // order does not matter for the result (§ exactness); the lane merely prunes with a slightly stale bound.  A lane
+        // order does not matter for the result (the reduction over leaves is a minimum over (t, record index)); the lane merely prunes with a slightly stale bound.  A lane
         // that reaches a second leaf while one is pending waits for the primitive path.
         if (has_ray && cur < 0 && !(prim_i < prim_end)) {
             const unsigned u = (unsigned)~cur;
@@ -584,7 +586,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
         // ---------------- per lane and iteration: a node step AND, when the wave runs its primitive path, one primitive test ----------------
         // Both records are requested at the top (the primitive record first), the primitive test runs while the node record is
         // still on its way, then the node step.  A lane in a leaf therefore keeps walking its stack while it works through the
-        // leaf's primitives; the order of visits does not matter for the result (§ exactness).
+        // leaf's primitives; the order of visits does not matter for the result (same reduction).
         const bool in_leaf = has_ray && prim_i < prim_end;
         const bool at_node = has_ray && cur >= 0 && cur < CUR_WAIT;
         const int n_leaf = __popcll(__ballot(in_leaf)), n_node = __popcll(__ballot(at_node));
@@ -916,7 +918,7 @@ void rt_launch_fill_int(hipStream_t s, int *p, int n, int v) {
     if (n > 0) hipLaunchKernelGGL(k_fill_int, dim3((n + 255) / 256), dim3(256), 0, s, p, n, v);
 }
 int rt_trace_block_threads() { return TRACE_BLOCK; }
-int rt_trace_resident_blocks() { return NUM_CUS * TRACE_RESIDENT_PER_CU; }
+int rt_trace_resident_blocks() { return g_num_cus * TRACE_RESIDENT_PER_CU; }
 
 static int g_trace_block_cap = 0;
 void rt_set_trace_block_cap(int cap) { g_trace_block_cap = cap; }
@@ -924,7 +926,7 @@ void rt_set_trace_block_cap(int cap) { g_trace_block_cap = cap; }
 // only start when the queue is already empty.  (Fewer, longer-running blocks for small launches: +27 % time at 200x120.)
 static int trace_blocks(int n) {
     int want = (n + TRACE_BLOCK - 1) / TRACE_BLOCK;
-    int cap = NUM_CUS * TRACE_RESIDENT_PER_CU;
+    int cap = g_num_cus * TRACE_RESIDENT_PER_CU;
     if (g_trace_block_cap > 0 && g_trace_block_cap < cap) cap = g_trace_block_cap;
     return want < cap ? (want < 1 ? 1 : want) : cap;
 }

@@ -1,4 +1,4 @@
-// PLY body decoding on the device ("PLY -> SoA arenas").
+// PLY body decoding on the device (the step before the scene upload: PLY file -> position and index arrays).
 //
 // Replaces what SceneParser.cpp:983-1023 does with happly's vector<array<double,3>> / vector<vector<size_t>>: vertex
 // positions become float (Vector3f(a[0], a[1], a[2]): a double property is rounded to float, a float property is taken as

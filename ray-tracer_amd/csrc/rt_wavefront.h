@@ -95,7 +95,8 @@ void rt_launch_backward(hipStream_t s, LevelBuf lv, int n, const int *n_dev, Lev
 void rt_launch_resolve(hipStream_t s, const DevCamera &cam, const int *pixel_list, int first_pixel, int n_pixels, LevelBuf lv0, int compact,
                        float *hdr, int *prim_id, float *prim_t);
 void rt_set_trace_block_cap(int cap);   // experiment hook: upper bound of the persistent grid (0 = default)
-int rt_trace_grid_threads();     // number of persistent threads the trace kernels are launched with
+void rt_set_num_cus(int n);      // compute units of the device (sizes the persistent grid)
+int rt_trace_grid_threads();     // most persistent threads a trace launch has (stride of the stack-overflow columns)
 int rt_trace_lds_stack_depth();  // stack entries kept in LDS per lane
 
 // rt_image.hip: frame post-processing (8-bit resolve, P3 text, tone mapping); all pointers are device pointers.

@@ -4,7 +4,7 @@
 src/scenes/other_dragon.xml needs scenes/ply/dragon_remeshed.ply, which is listed in .MISSING_LARGE_BLOBS.  Camera,
 lights, materials, recursion depth and the mirror floor are the ones of other_dragon.xml (:1-69); the mesh is a seeded
 procedural closed surface (a displaced (2,3) torus-knot tube) with exactly `n_tris` triangles whose bounding box is
-about 300 units and is centred near (0, 100, -20), as SURVEY.md §8d prescribes.
+about 300 units and is centred near (0, 100, -20), the stand-in the benchmark configuration uses for the missing dragon mesh.
 """
 import numpy as np
 
@@ -74,7 +74,7 @@ def dragon_standin_scene(n_tris=1_000_000, nx=800, ny=480, seed=7):
 
 
 def instanced_scene(n_instances=50, n_tris=1_000_000, nx=3840, ny=2160, spp=256, seed=7, perlin_table=None, checker=None):
-    """BASELINE.json config 5 (SURVEY.md §8d C5): a grid of MeshInstances of the stand-in mesh with distinct rotations,
+    """BASELINE.json config 5: a grid of MeshInstances of the stand-in mesh with distinct rotations,
     half of them with a Perlin bump_normal texture, on a floor with a replace_kd image texture."""
     b = SceneBuilder()
     s = b.soup

@@ -4,7 +4,7 @@ import sys
 
 import pytest
 import torch  # noqa: F401  -- first: torch ships its own HIP runtime; a process that loads /opt/rocm's copy (through
-#                             librt_mi355.so) before torch's ends with two runtimes and torch then finds no GPU (INTEGRATION.md)
+#                             librt_mi355.so) before torch's ends with two runtimes and torch then finds no GPU
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

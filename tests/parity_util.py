@@ -25,7 +25,11 @@ def compare_frames(gpu_hdr, cpu_hdr, gpu_id=None, cpu_id=None, gpu_t=None, cpu_t
     gpu_hdr = np.asarray(gpu_hdr)
     cpu_hdr = np.asarray(cpu_hdr)
     assert gpu_hdr.shape == cpu_hdr.shape
-    assert np.isfinite(gpu_hdr).all() == np.isfinite(cpu_hdr).all()
+    # non-finite values must sit at the same places on both sides, NaN against NaN and infinities of the same sign
+    assert np.array_equal(np.isfinite(gpu_hdr), np.isfinite(cpu_hdr)), "non-finite values at different pixels"
+    assert np.array_equal(np.isnan(gpu_hdr), np.isnan(cpu_hdr)), "NaN on one side, infinity on the other"
+    inf = np.isinf(cpu_hdr)
+    assert np.array_equal(np.sign(gpu_hdr[inf]), np.sign(cpu_hdr[inf])), "infinities of different sign"
     fin = np.isfinite(cpu_hdr) & np.isfinite(gpu_hdr)
     diff = np.abs(np.where(fin, gpu_hdr, 0).astype(np.float64) - np.where(fin, cpu_hdr, 0).astype(np.float64))
     bound = MAX_REL * np.maximum(1.0, np.abs(np.where(fin, cpu_hdr, 0)))

@@ -105,7 +105,7 @@ def test_more_objects_than_the_traversal_caches(rt, orc, gpu_ctx):
 
 
 def test_config4_with_dielectric(rt, orc, gpu_ctx, scene_path):
-    """BASELINE config 4 as SURVEY 8d words it: cornellbox_boxes_dynamic (motion-blurred instance, mirror + Phong) PLUS the
+    """BASELINE config 4 with its dielectric: cornellbox_boxes_dynamic (motion-blurred instance, mirror + Phong) PLUS the
     dielectric sphere of config 1, so that refraction queues diverge under motion blur.  Reduced spp / resolution."""
     soup = rt.SceneSoup.load(scene_path("cornellbox_boxes_dynamic"))
     soup._contig()

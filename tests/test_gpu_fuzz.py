@@ -107,7 +107,8 @@ def test_random_scene_matches_oracle(orc, gpu_ctx, seed, n_tris, depth, fancy):
 def test_noise_hit_of_a_sliver_is_not_pruned(orc, gpu_ctx, host_paths, monkeypatch):
     """Found by tools/fuzz_sweep.py (seed 12081): a 5 x 0.005 sliver whose Cramer determinants are rounding noise.  The reference
     accepts a "hit" on it 6.4 units outside the triangle's box and closer than the ray's real hit; a traversal that prunes boxes by
-    distance never tests it.  Subtrees holding such triangles carry DEV_REF_NOPRUNE (rt_device.h) — on both builder paths."""
+    distance never tests it.  The normal cone of a subtree that holds such a triangle never allows pruning (rt_cone.h: its
+    conditioning factor s is below the threshold for every ray) — on both builder paths."""
     seed = 12081
     if host_paths:
         for k in ("RT_HOST_BUILD", "RT_HOST_FLATTEN", "RT_HOST_INGEST"):

@@ -1,4 +1,4 @@
-"""GPU tests of the frame post-processing rows: 8-bit resolve, the P3 text of
+"""GPU tests of the frame post-processing: 8-bit resolve, the P3 text of
 Image::SaveImageAsPPM and the tone mapper, through the C-ABI (rt_image_encode, rt_tonemap) against the oracle's helpers.
 Bytes are compared exactly; the tone mapper within the float tolerance stated in the test."""
 import importlib

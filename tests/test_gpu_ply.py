@@ -1,4 +1,4 @@
-"""rt_ply_decode (PLY body -> positions + triangles on the device, SURVEY 8f rank 3) against the loader's numpy reader on the
+"""rt_ply_decode (PLY body -> positions + triangles on the device) against the loader's numpy reader on the
 same files: bit-exact positions, identical triangle lists.  Parity of the numpy reader itself: tests/test_ply_reader.py."""
 import importlib
 import os
@@ -52,7 +52,7 @@ def test_empty_and_truncated(rt, gpu_ctx, tmp_path):
 
 
 def test_million_triangles(rt, gpu_ctx, tmp_path):
-    """The config-2 stand-in mesh as a binary PLY (what SURVEY 8d asks the missing dragon_remeshed.ply to be replaced by)."""
+    """The config-2 stand-in mesh as a binary PLY (the stand-in for the missing dragon_remeshed.ply)."""
     synth = importlib.import_module("ray-tracer_amd.synth")
     pos, faces = synth.torus_knot_mesh(1_000_000, 7)
     path = os.path.join(tmp_path, "knot.ply")

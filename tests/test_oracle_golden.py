@@ -2,7 +2,7 @@
 path: the author's published 8-bit renders (reference src/results/*.png, stored decoded under tests/golden/).  They come
 from an older revision of the reference's sources, so the bound is loose per scene but tight in aggregate; for
 cornellbox_recursive the survey recorded what a fresh build of the CURRENT reference sources gives against the same PNG —
-27 232 differing pixels, max 220 — and the oracle reproduces exactly that count.
+27 232 differing pixels, max 220 (recorded when the reference could still be run) — and the oracle reproduces exactly that count.
 
 tests/golden/oracle_frames.json (tools/make_golden.py) additionally guards the oracle's own frames against regressions."""
 import hashlib
@@ -40,7 +40,7 @@ def test_oracle_vs_published_png(rt, frames, name):
     assert ref.shape == img8.shape
     d = np.abs(img8.astype(int) - ref.astype(int)).max(axis=2)
     within1 = float((d <= 1).mean())
-    assert within1 >= 0.95, (name, within1)                        # SURVEY §8c bound
+    assert within1 >= 0.95, (name, within1)                        # the author's PNGs come from an older revision: loose bound
     assert within1 >= FRAMES[name]["png_within_1"] - 1e-4          # and no worse than when the fixture was made
     if name == "cornellbox_recursive":
         assert int((d > 0).sum()) == 27232 and int(d.max()) == 220  # the figures the survey measured for the real reference
@@ -90,7 +90,7 @@ def test_oracle_vs_published_textured_png(rt, frames, name):
     if e.get("tonemapped"):
         # the one scene with <Tonemap>: the author published an 8-bit conversion of the EXR (converter unknown).  The oracle's tone
         # mapper on the float radiance + the scene's display gamma lands within 1.5 levels per block; on the 8-bit image (what the
-        # reference's current sources feed it, Q20) 5.8 — a plausibility bound for the operator, not a pin (DESIGN.md section 7b).
+        # reference's current sources feed it, Q20) 5.8 — a plausibility bound for the operator, not a pin.
         soup = rt.SceneSoup.load(os.path.join(ROOT, "scenes", name + ".npz"))
         key, burn, sat, gamma = soup.tonemap
         mapped, _ = importlib.import_module("oracle.orc").tonemap(hdr, key, burn, sat)

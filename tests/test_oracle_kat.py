@@ -227,7 +227,7 @@ def test_exr_restatement_layout(orc):
 
 
 def test_canonical_counts_fixture(rt, orc, scene_path):
-    """tests/golden/canonical_counts.json (SURVEY 8d yardstick, used by bench.py) is what the oracle counts: config 1 is
+    """tests/golden/canonical_counts.json (the canonical-traversal yardstick bench.py also reports) is what the oracle counts: config 1 is
     re-counted here, config 2 (9.3 M rays) is checked for its ray total and plausibility only."""
     import json, os
     fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "canonical_counts.json")))

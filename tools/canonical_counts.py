@@ -1,5 +1,5 @@
 """Generates tests/golden/canonical_counts.json: per configuration, the frame's rays through the canonical traversal that
-SURVEY.md 8(d) prices the algorithmic bytes with (CPU oracle; a few seconds per configuration on 8 cores)."""
+the benchmark prices the algorithmic bytes with (CPU oracle; a few seconds per configuration on 8 cores)."""
 import importlib
 import json
 import os
@@ -18,7 +18,7 @@ def main():
              ("config2 dragon_standin_1000000 800x480", synth.dragon_standin_scene(1_000_000, 800, 480), {})]
     for name, soup, kw in cases:
         c = orc.OracleScene(soup).canonical_counts(0, nthreads=os.cpu_count() or 1, **kw)
-        c["bytes_per_ray"] = (64 * c["nodes"] + 64 * c["tris"] + 16 * c["spheres"]) / c["rays"] + 64 + 32      # SURVEY 8d formula
+        c["bytes_per_ray"] = (64 * c["nodes"] + 64 * c["tris"] + 16 * c["spheres"]) / c["rays"] + 64 + 32      # 64 B per node visit and primitive test, 16 B per sphere, 64 + 32 B per ray
         out[name] = c
         print(name, c)
     json.dump(out, open(os.path.join(ROOT, "tests", "golden", "canonical_counts.json"), "w"), indent=1, sort_keys=True)

@@ -1,4 +1,4 @@
-"""Known limit of the bit-exact parity: rays that lie within 1e-9 ... 1e-4 rad of the plane of a triangle they
+"""Probe of the pruning rule: rays that lie within 1e-9 ... 1e-4 rad of the plane of a triangle they
 pass beside.  The reference's Cramer solve is then rounding noise for that (well-shaped) triangle and it may accept a "hit" with a
 nonsense t (64.0, 1024.0 ...) in a box the traversal has pruned by distance.  Prints the mismatch rate per angle decade.
 usage (GPU box): python3 tools/graze_probe.py"""
