@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: the resolution grows with N (each GPU keeps config 2's 800x480 share); strong: one fixed frame (800x480 at --spp samples) cut over the N GPUs")
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel (default: 1 = config 2 as quoted; 16 with --scaling strong)")
+    ap.add_argument("--eighth-share", action="store_true",
+                    help="also time the share one GPU of eight gets of this frame (every 8th tile); off by default so that the default run launches only whole frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-step", type=int, default=1, help="CPU baseline renders every k-th row of the frame")
     args = ap.parse_args()
@@ -210,7 +212,7 @@ def main():
 
     # the share one GPU of eight gets of this frame (every 8th 32x32 tile): what fixed costs leave of strong scaling
     share_ms = None
-    if world == 1:
+    if world == 1 and args.eighth_share:
         o8 = ctx.make_opts(seed=0, tile_size=TILE, tile_rank=0, tile_world=8, output_on_device=True, compact_output=True, timing=1)
         for _ in range(3):
             ctx.render_device(cd, o8, tg.tile_hdr.data_ptr(), None, None, abi.Stats())

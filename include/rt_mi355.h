@@ -116,6 +116,28 @@ typedef struct rt_object {
 #define RT_PRIM_BLURBOX 0x20000000  /* Primitive::bbox was taken after the motion-blur extension (Q5,Q29) */
 #define RT_PRIM_INDEX_MASK 0x1FFFFFFF
 
+/* <MeshInstance>: Mesh::Clone (reference src/Mesh.cpp:126-180, parser src/SceneParser.cpp:1075-1129).  The clone's triangles
+ * share the base mesh's vertices; the library creates them ("virtual" triangles): instance i owns the triangle indices
+ * n_triangles + (sum of n_triangles of the instances before it) + k, k < n_triangles, each with the vertex indices of base
+ * triangle first_triangle + k and this instance's object.  On the GPU build path the expansion runs on the device. */
+typedef struct rt_instance {
+    int64_t first_triangle;   /* first triangle of the base mesh (an explicit triangle, < rt_scene_desc.n_triangles) */
+    int64_t n_triangles;      /* number of triangles of the base mesh                                                */
+    int32_t object;           /* the clone's object: its own transform (instance matrix composed after the kept or reset
+                                 base matrix, Shape::SetTransformation src/Shape.cpp:29-39), material, motion blur   */
+    int32_t _pad;
+} rt_instance;                /* 24 bytes */
+
+/* A run of consecutive entries of Scene::primitives: shapes first, first + 1, ... first + count - 1 (triangle indices,
+ * explicit or virtual, or sphere indices when flags has RT_PRIM_SPHERE), every entry with the same flags.  A <Mesh> is two
+ * runs over its triangles (constructor, then SetMotionBlur with RT_PRIM_BLURBOX: Q5), a <MeshInstance> one run. */
+typedef struct rt_prim_run {
+    int64_t first;
+    int64_t count;
+    int32_t flags;            /* RT_PRIM_SPHERE and / or RT_PRIM_BLURBOX */
+    int32_t _pad;
+} rt_prim_run;                /* 24 bytes */
+
 typedef struct rt_scene_desc {
     uint32_t abi_version;     /* RT_ABI_VERSION */
     int32_t max_depth;        /* Scene::maxRecursionDepth   */
@@ -153,6 +175,15 @@ typedef struct rt_scene_desc {
     const rt_texture *textures;
     const uint8_t *texels;    /* image arena addressed by rt_texture.texel_offset */
     int64_t texels_bytes;
+
+    /* compact forms (all optional; zero / NULL = not used) */
+    int64_t n_instances;      /* <MeshInstance> clones for the library to expand (see rt_instance)                    */
+    const rt_instance *instances;
+    int64_t n_prim_runs;      /* when prim_runs != NULL it replaces prim_shape / n_prims (see rt_prim_run)             */
+    const rt_prim_run *prim_runs;
+    int32_t geometry_on_device; /* 1: vert_pos, vert_uv, tri_vert and tri_object are DEVICE pointers (for example filled by
+                                 rt_ply_decode_to): the geometry never visits the host                               */
+    int32_t _pad2;
 } rt_scene_desc;
 
 /* ---- camera: reference src/Camera.h:20-85 (constructor arguments, before SetupCameraCoordinateAxes) ---- */
@@ -329,7 +360,10 @@ typedef struct rt_tonemap_opts {
 int rt_tonemap(rt_ctx *ctx, const float *hdr_rgb, int nx, int ny, const rt_tonemap_opts *opts, float *out_rgb,
                float *out_params, double *ms_kernels);
 
-/* Body of a binary_little_endian PLY file as the caller's header parse describes it. */
+/* Body of a PLY file as the caller's header parse describes it: binary_little_endian, or ascii (format = 1).  For an ascii
+ * body "bytes" reads "tokens": vertex_stride = scalar properties per vertex line, pos_offset = token index of x, y, z,
+ * face_pre_bytes / face_post_bytes = scalar properties before / after the list; count_size and index_size are unused. */
+enum { RT_PLY_BINARY_LE = 0, RT_PLY_ASCII = 1 };
 typedef struct rt_ply_layout {
     uint32_t abi_version;
     int32_t pos_type;         /* type of the x, y, z properties: 0 = float (32 bit), 1 = double                          */
@@ -341,7 +375,9 @@ typedef struct rt_ply_layout {
     int32_t count_size;       /* bytes of the list's count field: 1, 2 or 4                                              */
     int32_t index_size;       /* bytes per index: 1, 2 or 4                                                              */
     int32_t face_post_bytes;  /* bytes of scalar properties after the list                                               */
-} rt_ply_layout;              /* 56 bytes */
+    int32_t format;           /* RT_PLY_BINARY_LE or RT_PLY_ASCII                                                        */
+    int32_t _pad;
+} rt_ply_layout;              /* 64 bytes */
 
 /* Replaces the PLY branch of the scene parser (src/SceneParser.cpp:983-1023: happly's getVertexPositions() rounded to
  * Vector3f, getFaceIndices() with a face of three indices kept as a triangle, a face of four split into (0,1,2), (2,3,0),
@@ -351,6 +387,18 @@ typedef struct rt_ply_layout {
  * here (rt_scene_upload does that).  No CPU fallback: RT_ERR_NO_DEVICE without a GPU. */
 int rt_ply_decode(rt_ctx *ctx, const void *vertex_bytes, const void *face_bytes, size_t face_bytes_size, const rt_ply_layout *layout,
                   float *out_pos, int32_t *out_tris, int64_t *out_n_tris, double *ms_kernels);
+/* For an ascii body (layout->format == RT_PLY_ASCII: what happly's parseASCII does, src/happly.h:2075-2095 — one element per line,
+ * tokens split at ' ', values through operator>> of the property's type) pass the whole body text as vertex_bytes and its
+ * length as face_bytes_size; face_bytes is ignored.  Decimal numbers are converted on the device where that is provably the
+ * correctly rounded result (at most 19 significant digits, a power of ten that is exact in the working type); the few tokens
+ * outside that are converted by the host with the very stream extraction the reference's library uses. */
+
+/* The same decoder with its output left in HBM: positions go to the DEVICE array d_out_pos [n_vertices * 3], triangles to the
+ * DEVICE array d_out_tris [up to 2 * n_faces * 3] with index_offset added to every vertex index (the mesh's first vertex
+ * inside a scene-wide vertex array).  Together with rt_scene_desc.geometry_on_device a mesh goes from the file bytes to the
+ * traversal arrays without its geometry visiting the host. */
+int rt_ply_decode_to(rt_ctx *ctx, const void *vertex_bytes, const void *face_bytes, size_t face_bytes_size, const rt_ply_layout *layout,
+                     float *d_out_pos, int32_t *d_out_tris, int32_t index_offset, int64_t *out_n_tris, double *ms_kernels);
 
 /* Host-only view of the BVH that rt_scene_upload would build (reference topology, BVHTree.cpp:39-153), so that tests
  * can compare it with an independent build without a GPU.  Leaves are listed in left-to-right DFS order.
@@ -381,7 +429,8 @@ int rt_cone_allows_prune(uint32_t word, const float *direction);
 void rt_host_bvh_free(rt_host_bvh *bvh);
 
 /* sizeof() of the ABI structs, in header order (0 rt_material, 1 rt_light, 2 rt_texture, 3 rt_object, 4 rt_scene_desc,
- * 5 rt_camera_desc, 6 rt_render_opts, 7 rt_stats, 8 rt_ray, 9 rt_hit, 10 rt_bvh_info, 11 rt_tonemap_opts, 12 rt_ply_layout); -1 for anything else. */
+ * 5 rt_camera_desc, 6 rt_render_opts, 7 rt_stats, 8 rt_ray, 9 rt_hit, 10 rt_bvh_info, 11 rt_tonemap_opts, 12 rt_ply_layout,
+ * 13 rt_instance, 14 rt_prim_run); -1 for anything else. */
 int rt_abi_sizeof(int which);
 
 uint32_t rt_abi_version(void);

@@ -48,6 +48,7 @@ def lib():
         L.orc_exr_half.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         L.orc_exr_half.restype = C.c_size_t
         L.orc_canonical_counts.argtypes = [C.c_void_p, C.POINTER(abi.CameraDesc), C.c_uint32, C.c_int, C.c_void_p]
+        L.orc_ply_read.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64)]
         L.orc_abi_version.restype = C.c_uint32
         assert L.orc_abi_version() == abi.RT_ABI_VERSION
         _LIB = L
@@ -56,8 +57,8 @@ def lib():
 
 class OracleScene:
     def __init__(self, soup):
-        self.soup = soup
-        self._desc = soup.desc()
+        self.soup = soup.expanded()          # the oracle takes the written-out scene (instances cloned, primitive list in full)
+        self._desc = self.soup.desc()
         self.h = lib().orc_scene_create(C.byref(self._desc))
         if not self.h:
             raise RuntimeError("orc_scene_create failed")
@@ -166,3 +167,17 @@ def exr_half(rgb):
     out = np.zeros(n, np.uint8)
     lib().orc_exr_half(v.ctypes.data, v.shape[1], v.shape[0], out.ctypes.data, n)
     return out.tobytes()
+
+
+def ply_read(file_bytes):
+    """A whole PLY file (bytes) through the oracle's restatement of the reference's loader (happly + the PLY branch of the
+    scene parser): (positions float32 [nv, 3], triangles int32 [nt, 3])."""
+    buf = np.frombuffer(bytes(file_bytes), np.uint8)
+    nv, nt = C.c_int64(0), C.c_int64(0)
+    if lib().orc_ply_read(buf.ctypes.data, len(buf), None, C.byref(nv), None, C.byref(nt)) != 0:
+        raise ValueError("the reference's PLY reader would reject this file")
+    pos = np.zeros((nv.value, 3), np.float32)
+    tris = np.zeros((nt.value, 3), np.int32)
+    rc = lib().orc_ply_read(buf.ctypes.data, len(buf), pos.ctypes.data, C.byref(nv), tris.ctypes.data, C.byref(nt))
+    assert rc == 0
+    return pos, tris

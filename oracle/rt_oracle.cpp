@@ -36,6 +36,7 @@
 #include <cstring>
 #include <limits>
 #include <random>
+#include <sstream>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -1676,5 +1677,143 @@ void orc_camera_ray(const rt_camera_desc *cam, int row, int col, int sample, uin
     o3[0] = r.o.x; o3[1] = r.o.y; o3[2] = r.o.z; d3[0] = r.d.x; d3[1] = r.d.y; d3[2] = r.d.z; *time = t;
 }
 uint32_t orc_abi_version(void) { return RT_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The PLY branch of the scene parser (SceneParser.cpp:975-1027) with the part of the vendored happly reader it goes through
+// (happly.h: parseHeader :1901-2060, parseASCII :2062-2095, parseBinary :2103-2140, getVertexPositions :1622-1640,
+// getFaceIndices :1673-1690): header lines, then one element after the other; an ascii element is one line per entry, split
+// at ' ' (tokenSplit :1390-1413), every value through operator>> of the property's declared type (:330-336, :494-512); a
+// binary property is a little-endian copy.  Vertex positions are x, y, z as double, rounded to float by Vector3f(a[0], a[1],
+// a[2]); a face of three indices is one triangle, a face of four is (0,1,2), (2,3,0), any other face is dropped.
+// Two-pass call: with out_pos == NULL only *nv and *n_tris are filled.  Returns 0, or -1 for a file happly would reject.
+namespace {
+std::string plyTrim(const std::string &in) {                            // happly.h:1379-1388
+    size_t a = 0;
+    while (a < in.size() && in[a] == ' ') a++;
+    size_t b = in.size();
+    while (b > a && (in[b - 1] == ' ' || in[b - 1] == '\n' || in[b - 1] == '\r')) b--;
+    return in.substr(a, b - a);
+}
+std::vector<std::string> plySplit(const std::string &input) {           // happly.h:1390-1413
+    std::vector<std::string> result;
+    size_t curr = 0, found = 0;
+    while ((found = input.find_first_of(' ', curr)) != std::string::npos) {
+        std::string token = plyTrim(input.substr(curr, found - curr));
+        if (token.size() > 0) result.push_back(token);
+        curr = found + 1;
+    }
+    std::string token = plyTrim(input.substr(curr));
+    if (token.size() > 0) result.push_back(token);
+    return result;
+}
+struct PlyProp { std::string name, type, countType; bool isList; };
+struct PlyElem { std::string name; size_t count; std::vector<PlyProp> props; };
+int plyTypeSize(const std::string &t) {
+    if (t == "char" || t == "uchar" || t == "int8" || t == "uint8") return 1;
+    if (t == "short" || t == "ushort" || t == "int16" || t == "uint16") return 2;
+    if (t == "int" || t == "uint" || t == "float" || t == "int32" || t == "uint32" || t == "float32") return 4;
+    if (t == "double" || t == "float64") return 8;
+    return 0;
+}
+// one ascii token through operator>> of the declared type, widened to double (getProperty<double> / getListPropertyAnySign)
+double plyAsciiValue(const std::string &tok, const std::string &t) {
+    std::istringstream iss(tok);
+    if (t == "float" || t == "float32") { float v = 0; iss >> v; return v; }
+    if (t == "double" || t == "float64") { double v = 0; iss >> v; return v; }
+    if (t == "char" || t == "int8" || t == "short" || t == "int16" || t == "int" || t == "int32") { long long v = 0; iss >> v; return (double)v; }
+    unsigned long long v = 0; iss >> v; return (double)v;               // unsigned types (8-bit ones are read as numbers, happly.h:106-130)
+}
+double plyBinaryValue(const unsigned char *p, const std::string &t) {
+    if (t == "float" || t == "float32") { float v; std::memcpy(&v, p, 4); return v; }
+    if (t == "double" || t == "float64") { double v; std::memcpy(&v, p, 8); return v; }
+    if (t == "char" || t == "int8") { int8_t v; std::memcpy(&v, p, 1); return v; }
+    if (t == "uchar" || t == "uint8") { uint8_t v; std::memcpy(&v, p, 1); return v; }
+    if (t == "short" || t == "int16") { int16_t v; std::memcpy(&v, p, 2); return v; }
+    if (t == "ushort" || t == "uint16") { uint16_t v; std::memcpy(&v, p, 2); return v; }
+    if (t == "int" || t == "int32") { int32_t v; std::memcpy(&v, p, 4); return v; }
+    uint32_t v; std::memcpy(&v, p, 4); return v;
+}
+}  // namespace
+
+int orc_ply_read(const void *file_bytes, size_t n_bytes, float *out_pos, int64_t *nv, int32_t *out_tris, int64_t *n_tris) {
+    if (!file_bytes || !nv || !n_tris) return -1;
+    const std::string file(static_cast<const char *>(file_bytes), n_bytes);
+    std::istringstream in(file);
+    std::string line;
+    std::getline(in, line);
+    if (plyTrim(line) != "ply") return -1;
+    std::getline(in, line);
+    std::vector<std::string> ft = plySplit(line);
+    if (ft.size() != 3 || ft[0] != "format" || ft[2] != "1.0") return -1;
+    const bool ascii = ft[1] == "ascii";
+    if (!ascii && ft[1] != "binary_little_endian") return -1;           // (big endian: not used by any caller here)
+    std::vector<PlyElem> elems;
+    for (;;) {
+        if (!in.good()) return -1;
+        std::getline(in, line);
+        if (line.compare(0, 7, "comment") == 0 || line.compare(0, 8, "obj_info") == 0) continue;
+        std::vector<std::string> tk = plySplit(line);
+        if (tk.empty()) continue;
+        if (tk[0] == "element" && tk.size() == 3) { PlyElem e; e.name = tk[1]; e.count = (size_t)std::stoull(tk[2]); elems.push_back(e); }
+        else if (tk[0] == "property" && !elems.empty()) {
+            PlyProp p;
+            if (tk.size() == 5 && tk[1] == "list") { p.isList = true; p.countType = tk[2]; p.type = tk[3]; p.name = tk[4]; }
+            else if (tk.size() == 3) { p.isList = false; p.type = tk[1]; p.name = tk[2]; }
+            else return -1;
+            if (!plyTypeSize(p.type) || (p.isList && !plyTypeSize(p.countType))) return -1;
+            elems.back().props.push_back(p);
+        } else if (tk[0] == "end_header") break;
+        else return -1;
+    }
+    // data: per element, per entry, every property in declaration order
+    std::vector<double> vx, vy, vz;
+    std::vector<std::vector<size_t>> faces;
+    size_t pos = (size_t)in.tellg();
+    const unsigned char *raw = static_cast<const unsigned char *>(file_bytes);
+    for (const PlyElem &e : elems) {
+        for (size_t i = 0; i < e.count; ++i) {
+            std::vector<std::string> tokens;
+            size_t it = 0;
+            if (ascii) { std::getline(in, line); tokens = plySplit(line); }
+            for (const PlyProp &p : e.props) {
+                std::vector<double> vals;
+                if (ascii) {
+                    size_t cnt = 1;
+                    if (p.isList) { if (it >= tokens.size()) return -1; std::istringstream iss(tokens[it++]); cnt = 0; iss >> cnt; }
+                    for (size_t k = 0; k < cnt; ++k) { if (it >= tokens.size()) return -1; vals.push_back(plyAsciiValue(tokens[it++], p.type)); }
+                } else {
+                    size_t cnt = 1;
+                    if (p.isList) { const int cs = plyTypeSize(p.countType); if (pos + cs > n_bytes) return -1; cnt = (size_t)plyBinaryValue(raw + pos, p.countType); pos += cs; }
+                    const int ts = plyTypeSize(p.type);
+                    for (size_t k = 0; k < cnt; ++k) { if (pos + ts > n_bytes) return -1; vals.push_back(plyBinaryValue(raw + pos, p.type)); pos += ts; }
+                }
+                if (e.name == "vertex" && !p.isList) {
+                    if (p.name == "x") vx.push_back(vals[0]); else if (p.name == "y") vy.push_back(vals[0]); else if (p.name == "z") vz.push_back(vals[0]);
+                } else if (e.name == "face" && p.isList && (p.name == "vertex_indices" || p.name == "vertex_index")) {
+                    std::vector<size_t> f;
+                    for (double v : vals) f.push_back((size_t)v);
+                    faces.push_back(f);
+                }
+            }
+        }
+    }
+    if (vx.size() != vy.size() || vx.size() != vz.size()) return -1;
+    *nv = (int64_t)vx.size();
+    int64_t nt = 0;
+    for (const std::vector<size_t> &v : faces) nt += v.size() == 4 ? 2 : (v.size() == 3 ? 1 : 0);
+    *n_tris = nt;
+    if (!out_pos && !out_tris) return 0;
+    if (out_pos) for (size_t i = 0; i < vx.size(); ++i) { out_pos[3 * i] = (float)vx[i]; out_pos[3 * i + 1] = (float)vy[i]; out_pos[3 * i + 2] = (float)vz[i]; }   // SceneParser.cpp:989-993
+    if (out_tris) {
+        size_t o = 0;
+        for (const std::vector<size_t> &v : faces) {                    // SceneParser.cpp:995-1021
+            if (v.size() == 4) {
+                const size_t q[6] = {v[0], v[1], v[2], v[2], v[3], v[0]};
+                for (int k = 0; k < 6; ++k) out_tris[o++] = (int32_t)q[k];
+            } else if (v.size() == 3) for (int k = 0; k < 3; ++k) out_tris[o++] = (int32_t)v[k];
+        }
+    }
+    return 0;
+}
 
 } // extern "C"

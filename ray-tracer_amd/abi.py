@@ -62,7 +62,15 @@ class SceneDesc(C.Structure):
         ("n_prims", C.c_int64), ("prim_shape", C.c_void_p),
         ("n_materials", C.c_int32), ("n_lights", C.c_int32), ("n_textures", C.c_int32), ("_pad1", C.c_int32),
         ("materials", C.c_void_p), ("lights", C.c_void_p), ("textures", C.c_void_p),
-        ("texels", C.c_void_p), ("texels_bytes", C.c_int64)]
+        ("texels", C.c_void_p), ("texels_bytes", C.c_int64),
+        ("n_instances", C.c_int64), ("instances", C.c_void_p), ("n_prim_runs", C.c_int64), ("prim_runs", C.c_void_p),
+        ("geometry_on_device", C.c_int32), ("_pad2", C.c_int32)]
+
+
+instance_dtype = np.dtype([("first_triangle", "<i8"), ("n_triangles", "<i8"), ("object", "<i4"), ("_pad", "<i4")])
+assert instance_dtype.itemsize == 24
+prim_run_dtype = np.dtype([("first", "<i8"), ("count", "<i8"), ("flags", "<i4"), ("_pad", "<i4")])
+assert prim_run_dtype.itemsize == 24
 
 
 class CameraDesc(C.Structure):
@@ -109,7 +117,10 @@ class TonemapOpts(C.Structure):
 class PlyLayout(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("pos_type", C.c_int32), ("n_vertices", C.c_int64), ("vertex_stride", C.c_int32),
                 ("pos_offset", C.c_int32 * 3), ("n_faces", C.c_int64), ("face_pre_bytes", C.c_int32), ("count_size", C.c_int32),
-                ("index_size", C.c_int32), ("face_post_bytes", C.c_int32)]
+                ("index_size", C.c_int32), ("face_post_bytes", C.c_int32), ("format", C.c_int32), ("_pad", C.c_int32)]
+
+
+RT_PLY_BINARY_LE, RT_PLY_ASCII = 0, 1
 
 
 class BvhInfo(C.Structure):

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <random>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -186,7 +187,7 @@ struct rt_ctx {
     // PLY decoding
     DevArray<uint8_t> d_ply_in, d_ply_tmp;
     DevArray<float> d_ply_pos;
-    DevArray<int> d_ply_tri, d_ply_cnt;
+    DevArray<int> d_ply_tri, d_ply_cnt, d_ply_flag;
     DevArray<long long> d_ply_off;
     DevArray<double> d_tm_partial;
 };
@@ -204,7 +205,7 @@ static void release_all(rt_ctx *c) {
     c->d_rays.release(); c->d_hits.release();
     c->d_img_in.release(); c->d_tm_lum.release(); c->d_tm_out.release(); c->d_tm_params.release();
     c->d_img8.release(); c->d_img_text.release(); c->d_img_tmp.release(); c->d_img_len.release(); c->d_img_off.release(); c->d_tm_partial.release();
-    c->d_ply_in.release(); c->d_ply_tmp.release(); c->d_ply_pos.release(); c->d_ply_tri.release(); c->d_ply_cnt.release(); c->d_ply_off.release();
+    c->d_ply_in.release(); c->d_ply_tmp.release(); c->d_ply_pos.release(); c->d_ply_tri.release(); c->d_ply_cnt.release(); c->d_ply_flag.release(); c->d_ply_off.release();
 }
 
 // Experiment switches of the traversal (thresholds of the persistent loop, pruning margin).  Only compiled into tuning builds
@@ -217,8 +218,10 @@ static void apply_tuning_knobs(rt_ctx *c) {
     DevSceneParams &p = c->dev.p;
     const DevSceneParams &d = c->host.params;
     p.tri_min_lanes = d.tri_min_lanes; p.donate = d.donate; p.refill_min_idle = d.refill_min_idle; p.donate_min_idle = d.donate_min_idle;
-    p.prune_err = d.prune_err; p.prune_rel = d.prune_rel; p.cone_off = 0;
+    p.prune_err = d.prune_err; p.prune_rel = d.prune_rel; p.cone_off = 0; p.min_chunk = d.min_chunk;
     rt_set_trace_block_cap(0);
+    if (const char *mc = getenv("RT_MIN_CHUNK")) p.min_chunk = clampi(atoi(mc), 1, 64);
+    if (const char *sb = getenv("RT_SMALL_RAYS_PER_BLOCK")) rt_set_small_rays_per_block(atoi(sb));
     if (const char *nc = getenv("RT_NO_CONE")) p.cone_off = atoi(nc) ? 1 : 0;
     if (const char *cap = getenv("RT_TRACE_BLOCK_CAP")) rt_set_trace_block_cap(std::max(0, atoi(cap)));
     if (const char *tml = getenv("RT_TRI_MIN_LANES")) p.tri_min_lanes = clampi(atoi(tml), 1, 64);
@@ -1085,18 +1088,87 @@ int rt_tonemap(rt_ctx *c, const float *hdr_rgb, int nx, int ny, const rt_tonemap
 }
 
 // ---- PLY body -> positions + triangles (rt_ply.hip) -----------------------------------------------------
-int rt_ply_decode(rt_ctx *c, const void *vertex_bytes, const void *face_bytes, size_t face_bytes_size, const rt_ply_layout *L, float *out_pos, int32_t *out_tris,
-                  int64_t *out_n_tris, double *ms_kernels) {
-    if (!c) return RT_ERR_INVALID;
+// Decodes into the context's device arrays d_ply_pos [3 nv] / d_ply_tri [3 n_tris]; the callers below copy them out.
+static int ply_decode_device(rt_ctx *c, const void *vertex_bytes, const void *face_bytes, size_t face_bytes_size, const rt_ply_layout *L, int64_t *out_n_tris,
+                             double *ms_kernels) {
     if (!L || L->abi_version != RT_ABI_VERSION) { c->error = "rt_ply_decode: abi_version mismatch"; return RT_ERR_ABI; }
     const int64_t nv = L->n_vertices, nf = L->n_faces;
+    const bool ascii = L->format == RT_PLY_ASCII;
     auto size_ok = [](int v) { return v == 1 || v == 2 || v == 4; };
-    if (nv < 0 || nf < 0 || !out_n_tris || (nv > 0 && (!vertex_bytes || !out_pos)) || (nf > 0 && (!face_bytes || !out_tris)) || (L->pos_type != 0 && L->pos_type != 1) ||
-        !size_ok(L->count_size) || !size_ok(L->index_size) || L->face_pre_bytes < 0 || L->face_post_bytes < 0) { c->error = "rt_ply_decode: bad argument"; return RT_ERR_INVALID; }
+    if (nv < 0 || nf < 0 || !out_n_tris || (nv > 0 && !vertex_bytes) || (nf > 0 && !ascii && !face_bytes) || (L->pos_type != 0 && L->pos_type != 1) ||
+        (L->format != RT_PLY_BINARY_LE && L->format != RT_PLY_ASCII) || (!ascii && (!size_ok(L->count_size) || !size_ok(L->index_size))) || L->face_pre_bytes < 0 ||
+        L->face_post_bytes < 0) { c->error = "rt_ply_decode: bad argument"; return RT_ERR_INVALID; }
+    if (nv > 0x7fffffffLL || nf > 0x3fffffffLL) { c->error = "rt_ply_decode: more than 2^31 vertices or 2^30 faces"; return RT_ERR_TOO_LARGE; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    HIP_TRY(c, c->d_ply_pos.ensure((size_t)nv * 3 + 1));
+    HIP_TRY(c, c->d_ply_tri.ensure((size_t)nf * 6 + 1));
+    HIP_TRY(c, c->d_ply_cnt.ensure(2 * ((size_t)nf + 1) + 4));
+    int *d_flag = c->d_ply_cnt.p + 2 * ((size_t)nf + 1);
+    HIP_TRY(c, hipMemsetAsync(d_flag, 0, 4 * sizeof(int), s));
+    EventPair ev;
+    int64_t n_tris = 0;
+    if (ascii) {
+        // the whole body text: vertex lines, then face lines (src/happly.h:2075-2095)
+        const size_t n_text = face_bytes_size;
+        if (n_text > 0x7ffffff0ull) { c->error = "rt_ply_decode: ascii body larger than 2 GiB"; return RT_ERR_TOO_LARGE; }
+        for (int k = 0; k < 3; ++k)
+            if (L->pos_offset[k] < 0 || L->pos_offset[k] >= L->vertex_stride) { c->error = "rt_ply_decode: position token outside the vertex line"; return RT_ERR_INVALID; }
+        const int64_t n_lines = nv + nf;
+        const int hard_cap = 1 << 16;
+        size_t scan_bytes = 0, scan2 = 0;
+        HIP_TRY(c, rt_ply_ascii_scan_bytes((int64_t)n_text, &scan_bytes));
+        HIP_TRY(c, rt_ply_scan_bytes(nf, &scan2));
+        HIP_TRY(c, c->d_ply_tmp.ensure(std::max(scan_bytes, scan2) + 16));
+        HIP_TRY(c, c->d_ply_in.ensure(n_text + 16));
+        HIP_TRY(c, c->d_ply_off.ensure((size_t)n_lines + 2));
+        HIP_TRY(c, c->d_ply_flag.ensure(2 * (n_text + 1) + 1 + 3 * (size_t)hard_cap));
+        int *d_nl = c->d_ply_flag.p, *d_scan = d_nl + (n_text + 1), *d_hard = d_scan + (n_text + 1);
+        if (n_text) HIP_TRY(c, hipMemcpyAsync(c->d_ply_in.p, vertex_bytes, n_text, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemsetAsync(c->d_ply_off.p, 0, ((size_t)n_lines + 2) * sizeof(long long), s));
+        HIP_TRY(c, hipMemsetAsync(d_hard, 0, sizeof(int), s));
+        HIP_TRY(c, ev.start(ms_kernels != nullptr, s));
+        HIP_TRY(c, rt_ply_ascii_lines(s, c->d_ply_in.p, (int64_t)n_text, d_nl, d_scan, c->d_ply_tmp.p, scan_bytes, n_lines, c->d_ply_off.p));
+        HIP_TRY(c, rt_ply_ascii_vertices(s, c->d_ply_in.p, c->d_ply_off.p, (int64_t)n_text, nv, L->pos_offset, L->pos_type, c->d_ply_pos.p, d_hard, hard_cap, d_flag));
+        int *d_ntri = c->d_ply_cnt.p, *d_toff = c->d_ply_cnt.p + (nf + 1);
+        HIP_TRY(c, rt_ply_ascii_faces_count(s, c->d_ply_in.p, c->d_ply_off.p, (int64_t)n_text, nv, nf, L->face_pre_bytes, d_ntri, d_toff, c->d_ply_tmp.p, scan2, d_flag));
+        HIP_TRY(c, rt_ply_ascii_faces_write(s, c->d_ply_in.p, c->d_ply_off.p, (int64_t)n_text, nv, nf, L->face_pre_bytes, d_toff, c->d_ply_tri.p, d_flag));
+        HIP_TRY(c, ev.stop(s));
+        int total = 0, bad = 0, n_lines_found = 0, n_hard = 0;
+        HIP_TRY(c, hipMemcpyAsync(&total, d_toff + nf, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(&bad, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(&n_lines_found, d_scan + n_text, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(&n_hard, d_hard, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        const bool last_open = n_text > 0 && static_cast<const char *>(vertex_bytes)[n_text - 1] != '\n';
+        if ((int64_t)n_lines_found + (last_open ? 1 : 0) < n_lines) { c->error = "rt_ply_decode: ascii body has fewer lines than vertices + faces"; return RT_ERR_INVALID; }
+        if (bad & 1) { c->error = "rt_ply_decode: a vertex line has fewer values than the header declares"; return RT_ERR_INVALID; }
+        if (bad & 2) { c->error = "rt_ply_decode: a face line is not a count followed by non-negative integer indices"; return RT_ERR_INVALID; }
+        if (n_hard > hard_cap) { c->error = "rt_ply_decode: too many numbers outside the device's exact decimal conversion"; return RT_ERR_TOO_LARGE; }
+        if (n_hard > 0) {
+            // tokens the device could not prove correct: the reference library's own conversion (operator>> of the property's type)
+            std::vector<int> rec(3 * (size_t)n_hard);
+            HIP_TRY(c, hipMemcpyAsync(rec.data(), d_hard + 1, rec.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            const char *text = static_cast<const char *>(vertex_bytes);
+            std::vector<float> fixed((size_t)n_hard);
+            for (int h = 0; h < n_hard; ++h) {
+                size_t a = (size_t)rec[3 * h + 2], b = a;
+                while (b < n_text && text[b] != ' ' && text[b] != '\n' && text[b] != '\r') ++b;
+                std::istringstream iss(std::string(text + a, b - a));
+                if (L->pos_type) { double v = 0; iss >> v; fixed[(size_t)h] = (float)v; } else { float v = 0; iss >> v; fixed[(size_t)h] = v; }
+                HIP_TRY(c, hipMemcpyAsync(c->d_ply_pos.p + 3 * (size_t)rec[3 * h] + rec[3 * h + 1], &fixed[(size_t)h], sizeof(float), hipMemcpyHostToDevice, s));
+            }
+            HIP_TRY(c, hipStreamSynchronize(s));
+        }
+        n_tris = total;
+        *out_n_tris = n_tris;
+        if (ms_kernels) *ms_kernels = ev.ms();
+        return RT_OK;
+    }
     const int csz = L->pos_type ? 8 : 4;
     for (int k = 0; k < 3; ++k)
         if (L->pos_offset[k] < 0 || L->pos_offset[k] + csz > L->vertex_stride) { c->error = "rt_ply_decode: position offset outside the vertex record"; return RT_ERR_INVALID; }
-    if (nv > 0x7fffffffLL || nf > 0x3fffffffLL) { c->error = "rt_ply_decode: more than 2^31 vertices or 2^30 faces"; return RT_ERR_TOO_LARGE; }
     const uint8_t *fb = static_cast<const uint8_t *>(face_bytes);
     auto count_at = [&](size_t pos) { unsigned v = fb[pos]; if (L->count_size >= 2) v |= (unsigned)fb[pos + 1] << 8; if (L->count_size == 4) v |= (unsigned)fb[pos + 2] << 16 | (unsigned)fb[pos + 3] << 24; return v; };
     const size_t fixed = (size_t)L->face_pre_bytes + L->count_size + L->face_post_bytes;
@@ -1105,25 +1177,16 @@ int rt_ply_decode(rt_ctx *c, const void *vertex_bytes, const void *face_bytes, s
         if (face_bytes_size < fixed) { c->error = "rt_ply_decode: face data truncated"; return RT_ERR_INVALID; }
         k0 = count_at(L->face_pre_bytes);
     }
-    HIP_TRY(c, hipSetDevice(c->device));
-    hipStream_t s = c->stream;
     const size_t vbytes = (size_t)nv * L->vertex_stride;
     HIP_TRY(c, c->d_ply_in.ensure(vbytes + face_bytes_size + 16));
-    HIP_TRY(c, c->d_ply_pos.ensure((size_t)nv * 3 + 1));
-    HIP_TRY(c, c->d_ply_tri.ensure((size_t)nf * 6 + 1));
-    HIP_TRY(c, c->d_ply_cnt.ensure(2 * ((size_t)nf + 1) + 1));
     uint8_t *d_vb = c->d_ply_in.p, *d_fb = c->d_ply_in.p + vbytes;
     if (vbytes) HIP_TRY(c, hipMemcpyAsync(d_vb, vertex_bytes, vbytes, hipMemcpyHostToDevice, s));
     if (nf > 0) HIP_TRY(c, hipMemcpyAsync(d_fb, face_bytes, face_bytes_size, hipMemcpyHostToDevice, s));
-    int *d_flag = c->d_ply_cnt.p + 2 * ((size_t)nf + 1);
-    HIP_TRY(c, hipMemsetAsync(d_flag, 0, sizeof(int), s));
-    EventPair ev;
     HIP_TRY(c, ev.start(ms_kernels != nullptr, s));
     HIP_TRY(c, rt_ply_vertices(s, d_vb, nv, L->vertex_stride, L->pos_offset, L->pos_type, c->d_ply_pos.p));
     // one face size for the whole file?  (the records are then at i * record size; the kernel checks every count)
     const size_t rec0 = fixed + (size_t)k0 * L->index_size;
     bool uniform = nf > 0 && rec0 <= face_bytes_size / (size_t)nf;
-    int64_t n_tris = 0;
     if (uniform) {
         HIP_TRY(c, rt_ply_faces_uniform(s, d_fb, nf, L->face_pre_bytes, L->count_size, L->index_size, L->face_post_bytes, k0, c->d_ply_tri.p, d_flag));
         int flag = 0;
@@ -1156,11 +1219,39 @@ int rt_ply_decode(rt_ctx *c, const void *vertex_bytes, const void *face_bytes, s
         n_tris = total;
     }
     HIP_TRY(c, ev.stop(s));
-    if (nv > 0) HIP_TRY(c, hipMemcpyAsync(out_pos, c->d_ply_pos.p, (size_t)nv * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
-    if (n_tris > 0) HIP_TRY(c, hipMemcpyAsync(out_tris, c->d_ply_tri.p, (size_t)n_tris * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     *out_n_tris = n_tris;
     if (ms_kernels) *ms_kernels = ev.ms();
+    return RT_OK;
+}
+
+int rt_ply_decode(rt_ctx *c, const void *vertex_bytes, const void *face_bytes, size_t face_bytes_size, const rt_ply_layout *L, float *out_pos, int32_t *out_tris,
+                  int64_t *out_n_tris, double *ms_kernels) {
+    if (!c) return RT_ERR_INVALID;
+    if (L && ((L->n_vertices > 0 && !out_pos) || (L->n_faces > 0 && !out_tris))) { c->error = "rt_ply_decode: bad argument"; return RT_ERR_INVALID; }
+    int64_t n_tris = 0;
+    const int rc = ply_decode_device(c, vertex_bytes, face_bytes, face_bytes_size, L, &n_tris, ms_kernels);
+    if (rc != RT_OK) return rc;
+    hipStream_t s = c->stream;
+    if (L->n_vertices > 0) HIP_TRY(c, hipMemcpyAsync(out_pos, c->d_ply_pos.p, (size_t)L->n_vertices * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (n_tris > 0) HIP_TRY(c, hipMemcpyAsync(out_tris, c->d_ply_tri.p, (size_t)n_tris * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    *out_n_tris = n_tris;
+    return RT_OK;
+}
+
+int rt_ply_decode_to(rt_ctx *c, const void *vertex_bytes, const void *face_bytes, size_t face_bytes_size, const rt_ply_layout *L, float *d_out_pos, int32_t *d_out_tris,
+                     int32_t index_offset, int64_t *out_n_tris, double *ms_kernels) {
+    if (!c) return RT_ERR_INVALID;
+    if (L && ((L->n_vertices > 0 && !d_out_pos) || (L->n_faces > 0 && !d_out_tris))) { c->error = "rt_ply_decode_to: bad argument"; return RT_ERR_INVALID; }
+    int64_t n_tris = 0;
+    const int rc = ply_decode_device(c, vertex_bytes, face_bytes, face_bytes_size, L, &n_tris, ms_kernels);
+    if (rc != RT_OK) return rc;
+    hipStream_t s = c->stream;
+    if (L->n_vertices > 0) HIP_TRY(c, hipMemcpyAsync(d_out_pos, c->d_ply_pos.p, (size_t)L->n_vertices * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, rt_ply_offset_copy(s, c->d_ply_tri.p, d_out_tris, 3 * n_tris, index_offset));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    *out_n_tris = n_tris;
     return RT_OK;
 }
 
@@ -1228,6 +1319,8 @@ int rt_abi_sizeof(int which) {
     case 10: return (int)sizeof(rt_bvh_info);
     case 11: return (int)sizeof(rt_tonemap_opts);
     case 12: return (int)sizeof(rt_ply_layout);
+    case 13: return (int)sizeof(rt_instance);
+    case 14: return (int)sizeof(rt_prim_run);
     default: return -1;
     }
 }

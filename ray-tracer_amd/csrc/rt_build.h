@@ -75,7 +75,10 @@ struct RtGpuIngest {
 };
 // RT_OK, a negative rt_status, or 1 = "use the host loops" (a vertex shared by two smooth objects).  The description must have
 // been range-checked; sphere_rec holds the sphere records (host).
-int rt_ingest_gpu(const rt_scene_desc *d, const std::vector<DevObject> &objects, const std::vector<DevPrim> &sphere_rec, RtGpuIngest &out, std::string &err);
+// n_tris_total / n_prims_total: triangle and primitive counts after the expansion of rt_instance / rt_prim_run records, which
+// happens here, in HBM; with geometry_on_device the vertex and triangle arrays of the description are device memory already.
+int rt_ingest_gpu(const rt_scene_desc *d, int64_t n_tris_total, int64_t n_prims_total, const std::vector<DevObject> &objects, const std::vector<DevPrim> &sphere_rec,
+                  RtGpuIngest &out, std::string &err);
 
 // Returns 0 or a negative rt_status; `err` receives a message.  gpu_build: build the tree with rt_bvh_gpu_build when the scene
 // has at least RT_GPU_BUILD_MIN_PRIMS primitives (the flattening stays on the host); the result is the same either way.

@@ -80,6 +80,77 @@ float cone_k_of_matrix(const float *M) {
 
 }  // namespace
 
+// The compact forms of a scene description (rt_instance, rt_prim_run, device-resident geometry) written out on the host: what
+// Mesh::Clone (src/Mesh.cpp:126-180) and the pushes into Scene::primitives (src/Mesh.cpp:57-58, 182-192) produce.  Used by
+// the host build path (small scenes, A/B runs); the device path expands them in rt_ingest.hip.
+struct HostExpanded {
+    std::vector<float> vert_pos, vert_uv;
+    std::vector<int32_t> tri_vert, tri_object, prim_shape;
+};
+static thread_local bool g_force_host_ingest = false;      // set while a scene the device ingest handed back is built by the host loops
+static bool scene_is_compact(const rt_scene_desc *d) { return d->n_instances > 0 || d->prim_runs != nullptr || d->geometry_on_device != 0; }
+// totals after expansion; false + err on an inconsistent record
+static bool compact_totals(const rt_scene_desc *d, int64_t &nT_total, int64_t &nP_total, std::string &err) {
+    nT_total = d->n_triangles;
+    if (d->n_instances < 0 || d->n_prim_runs < 0 || (d->n_instances && !d->instances)) { err = "bad instance / primitive-run table"; return false; }
+    for (int64_t i = 0; i < d->n_instances; ++i) {
+        const rt_instance &in = d->instances[i];
+        if (in.first_triangle < 0 || in.n_triangles < 0 || in.first_triangle + in.n_triangles > d->n_triangles) { err = "instance references triangles outside the explicit ones"; return false; }
+        if (in.object < 0 || in.object >= d->n_objects) { err = "instance references a missing object"; return false; }
+        nT_total += in.n_triangles;
+        if (nT_total > RT_PRIM_INDEX_MASK) { err = "too many triangles (limit 2^29-1)"; return false; }
+    }
+    nP_total = d->n_prims;
+    if (d->prim_runs) {
+        nP_total = 0;
+        for (int64_t i = 0; i < d->n_prim_runs; ++i) {
+            const rt_prim_run &r = d->prim_runs[i];
+            const int64_t limit = (r.flags & RT_PRIM_SPHERE) ? d->n_spheres : nT_total;
+            if (r.first < 0 || r.count < 0 || r.first + r.count > limit || (r.flags & ~(RT_PRIM_SPHERE | RT_PRIM_BLURBOX))) { err = "primitive run references a missing shape"; return false; }
+            nP_total += r.count;
+            if (nP_total > RT_PRIM_INDEX_MASK) { err = "too many primitives (limit 2^29-1)"; return false; }
+        }
+    }
+    return true;
+}
+static int expand_on_host(const rt_scene_desc *d, HostExpanded &x, rt_scene_desc &dd, std::string &err) {
+    int64_t nT_total = 0, nP_total = 0;
+    if (!compact_totals(d, nT_total, nP_total, err)) return RT_ERR_INVALID;
+    dd = *d;
+    x.tri_vert.resize(3 * (size_t)nT_total); x.tri_object.resize((size_t)nT_total);
+    if (d->geometry_on_device) {
+        x.vert_pos.resize(3 * (size_t)d->n_vertices);
+        if (d->n_vertices && hipMemcpy(x.vert_pos.data(), d->vert_pos, x.vert_pos.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { err = "copy of device-resident vertices failed"; return RT_ERR_HIP; }
+        if (d->vert_uv) {
+            x.vert_uv.resize(2 * (size_t)d->n_vertices);
+            if (d->n_vertices && hipMemcpy(x.vert_uv.data(), d->vert_uv, x.vert_uv.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { err = "copy of device-resident uv failed"; return RT_ERR_HIP; }
+        }
+        if (d->n_triangles && (hipMemcpy(x.tri_vert.data(), d->tri_vert, 3 * (size_t)d->n_triangles * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+                               hipMemcpy(x.tri_object.data(), d->tri_object, (size_t)d->n_triangles * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)) { err = "copy of device-resident triangles failed"; return RT_ERR_HIP; }
+        dd.vert_pos = x.vert_pos.data(); dd.vert_uv = d->vert_uv ? x.vert_uv.data() : nullptr;
+    } else {
+        if (d->n_triangles) { std::memcpy(x.tri_vert.data(), d->tri_vert, 3 * (size_t)d->n_triangles * sizeof(int32_t)); std::memcpy(x.tri_object.data(), d->tri_object, (size_t)d->n_triangles * sizeof(int32_t)); }
+    }
+    int64_t t = d->n_triangles;
+    for (int64_t i = 0; i < d->n_instances; ++i) {
+        const rt_instance &in = d->instances[i];
+        for (int64_t k = 0; k < in.n_triangles; ++k, ++t) {
+            for (int q = 0; q < 3; ++q) x.tri_vert[3 * (size_t)t + q] = x.tri_vert[3 * (size_t)(in.first_triangle + k) + q];
+            x.tri_object[(size_t)t] = in.object;
+        }
+    }
+    dd.n_triangles = nT_total; dd.tri_vert = x.tri_vert.data(); dd.tri_object = x.tri_object.data();
+    if (d->prim_runs) {
+        x.prim_shape.resize((size_t)nP_total);
+        size_t p = 0;
+        for (int64_t i = 0; i < d->n_prim_runs; ++i)
+            for (int64_t k = 0; k < d->prim_runs[i].count; ++k) x.prim_shape[p++] = (int32_t)(d->prim_runs[i].first + k) | d->prim_runs[i].flags;
+        dd.n_prims = nP_total; dd.prim_shape = x.prim_shape.data();
+    }
+    dd.n_instances = 0; dd.instances = nullptr; dd.n_prim_runs = 0; dd.prim_runs = nullptr; dd.geometry_on_device = 0;
+    return RT_OK;
+}
+
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err, int gpu_build, RtGpuScene *device_out) {
@@ -92,8 +163,22 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
         d->n_lights < 0 || d->n_textures < 0) { err = "negative count in scene description"; return RT_ERR_INVALID; }
     if (d->n_prims > RT_PRIM_INDEX_MASK || d->n_triangles > RT_PRIM_INDEX_MASK) { err = "too many primitives (limit 2^29-1)"; return RT_ERR_TOO_LARGE; }
     if ((d->n_triangles && (!d->tri_vert || !d->tri_object || !d->vert_pos)) || (d->n_spheres && (!d->sph_center_radius || !d->sph_object)) ||
-        (d->n_objects && !d->objects) || (d->n_prims && !d->prim_shape) || (d->n_materials && !d->materials) ||
+        (d->n_objects && !d->objects) || (d->n_prims && !d->prim_shape && !d->prim_runs) || (d->n_materials && !d->materials) ||
         (d->n_lights && !d->lights) || (d->n_textures && !d->textures)) { err = "NULL array with non-zero count"; return RT_ERR_INVALID; }
+    // compact forms: instances / primitive runs / device-resident geometry.  The device path below expands them in HBM; every
+    // other path gets them written out here first.
+    const bool compact = scene_is_compact(d);
+    int64_t nT_total = d->n_triangles, nP_total = d->n_prims;
+    if (compact && !compact_totals(d, nT_total, nP_total, err)) return RT_ERR_INVALID;
+    const bool device_path = nP_total > 0 && device_out && (gpu_build == 2 || (gpu_build == 1 && nP_total >= RT_GPU_BUILD_MIN_PRIMS && !getenv("RT_HOST_BUILD"))) &&
+                             !getenv("RT_HOST_FLATTEN") && !getenv("RT_HOST_INGEST") && !g_force_host_ingest;
+    if (compact && !device_path) {
+        HostExpanded x;
+        rt_scene_desc dd;
+        const int rc = expand_on_host(d, x, dd, err);
+        if (rc != RT_OK) return rc;
+        return rt_build_host_scene(&dd, hs, err, gpu_build, device_out);
+    }
 
     // ---- tables copied as they are ---------------------------------------------------------------
     hs.materials.assign(d->materials, d->materials + d->n_materials);
@@ -130,13 +215,13 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
     }
 
     // ---- large scenes: shape setup, build and flattening all on the device (rt_ingest.hip, rt_bvh_gpu.hip) -----------
-    const bool want_gpu = d->n_prims > 0 && (gpu_build == 2 || (gpu_build == 1 && d->n_prims >= RT_GPU_BUILD_MIN_PRIMS && !getenv("RT_HOST_BUILD")));
+    const bool want_gpu = nP_total > 0 && (gpu_build == 2 || (gpu_build == 1 && nP_total >= RT_GPU_BUILD_MIN_PRIMS && !getenv("RT_HOST_BUILD")));
     bool device_done = false;
     int maxDepth = 0;
-    if (want_gpu && device_out && !getenv("RT_HOST_FLATTEN") && !getenv("RT_HOST_INGEST")) {
-        const int64_t nT = d->n_triangles, nS = d->n_spheres, nP = d->n_prims;
-        for (int64_t t = 0; t < nT; ++t) {                                // the range checks of the host loops below
-            const int32_t *iv = d->tri_vert + 3 * t;
+    if (device_path) {
+        const int64_t nT = nT_total, nS = d->n_spheres, nP = nP_total;
+        for (int64_t t = 0; t < d->n_triangles && !d->geometry_on_device; ++t) {      // the range checks of the host loops below (device-resident
+            const int32_t *iv = d->tri_vert + 3 * t;                                      // geometry is checked by rt_ingest.hip)
             const int32_t ob = d->tri_object[t];
             if (ob < 0 || ob >= d->n_objects) { err = "triangle references a missing object"; return RT_ERR_INVALID; }
             for (int k = 0; k < 3; ++k) if (iv[k] < 0 || iv[k] >= d->n_vertices) { err = "triangle references a missing vertex"; return RT_ERR_INVALID; }
@@ -151,14 +236,24 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
             r.e1[0] = d->sph_center_radius[4 * s + 3];
             r.object = ob; r.shape = (int32_t)s | RT_PRIM_SPHERE; r.kind = DEV_PRIM_SPHERE;
         }
-        for (int64_t i = 0; i < nP; ++i) {
+        for (int64_t i = 0; i < nP && !d->prim_runs; ++i) {               // (runs were checked by compact_totals)
             const int32_t ref = d->prim_shape[i];
             if ((ref & RT_PRIM_INDEX_MASK) >= ((ref & RT_PRIM_SPHERE) ? nS : nT)) { err = "primitive references a missing shape"; return RT_ERR_INVALID; }
         }
         lap("tables, range checks");
         RtGpuIngest ing;
-        const int irc = rt_ingest_gpu(d, hs.objects, sphereRec, ing, err);
+        const int irc = rt_ingest_gpu(d, nT_total, nP_total, hs.objects, sphereRec, ing, err);
         if (irc < 0) return irc;
+        if (irc == 1 && compact) {        // a vertex shared by two smooth objects: the host loops, on the written-out scene
+            HostExpanded x;
+            rt_scene_desc dd;
+            const int rc = expand_on_host(d, x, dd, err);
+            if (rc != RT_OK) return rc;
+            g_force_host_ingest = true;
+            const int rc2 = rt_build_host_scene(&dd, hs, err, gpu_build, device_out);
+            g_force_host_ingest = false;
+            return rc2;
+        }
         if (irc == RT_OK) {
             const bool ok = rt_bvh_gpu_build_flatten(ing.pbox, nP, ing.shape_rec, nT + nS, ing.pshape, hs.objects, *device_out, err, /*inputs_on_device=*/true);
             if (!ok) { ing.release(); return RT_ERR_HIP; }
@@ -472,6 +567,7 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
     hs.params.n_lights = d->n_lights; hs.params.n_materials = d->n_materials; hs.params.n_textures = d->n_textures;
     hs.params.bvh_depth = maxDepth;
     hs.params.flt_max = 3.402823466e+38f;
+    hs.params.min_chunk = 64;
     hs.params.tri_min_lanes = RT_TRI_MIN_LANES;
     hs.params.donate = 1;
     hs.params.refill_min_idle = RT_REFILL_MIN_IDLE;

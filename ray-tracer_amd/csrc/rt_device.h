@@ -105,6 +105,7 @@ struct DevSceneParams {
     float isect_eps_p1;       // 1 + isect_eps in float (Triangle.cpp:219): a kernel argument so that it stays in a scalar register
     float flt_max;            // FLT_MAX as a kernel argument: a literal would sit in a vector register of the traversal loop, which
                               // the register allocator spills and reloads (with a wait for every outstanding load) once per node step
+    int32_t min_chunk;        // smallest number of rays a wave of the traversal reserves at a time (small launches)
     int32_t cone_off;         // tuning builds only (RT_NO_CONE): prune far children without the normal-cone test (NOT exact)
 };
 #define RT_NO_ROOT 0x7fffffff

@@ -397,6 +397,15 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
     unsigned long long ray_t0 = 0;
     bool exhausted = false;          // wave-uniform: the global queue has no more chunks
     int chunk_next = 0, chunk_end = 0;
+    // Rays a wave reserves per atomic.  A launch with fewer rays than the grid has lanes hands every wave an equal share instead
+    // of 64 to the first waves and none to the rest: the launch then lasts as long as its longest ray, and the idle lanes of
+    // every wave can start taking over parts of its long rays (donation) at once.
+    int chunk = TRACE_CHUNK;
+    {
+        const int waves = gridDim.x * (TRACE_BLOCK / 64);
+        const int share = (n + waves - 1) / waves;
+        if (share < TRACE_CHUNK) chunk = share < sc.p.min_chunk ? sc.p.min_chunk : share;
+    }
     // work donation (see the retire block): a lane may hand the bottom entry of its stack to an idle lane of the wave
     int sbase = 0;                   // the stack is [sbase, sp): entries below sbase were given away
     int plane = lane;                // lane this part of a ray reports to (its own lane: it owns the ray)
@@ -465,11 +474,11 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                     // 3a. new rays from the wave's chunk of the queue
                     if (chunk_next >= chunk_end) {
                         int base = 0;
-                        if (lane == 0) base = atomicAdd(fetch_counter, TRACE_CHUNK);
+                        if (lane == 0) base = atomicAdd(fetch_counter, chunk);
                         base = __shfl(base, 0);
                         chunk_next = base;
-                        chunk_end = base + TRACE_CHUNK < n ? base + TRACE_CHUNK : n;
-                        if (base + TRACE_CHUNK >= n) exhausted = true;
+                        chunk_end = base + chunk < n ? base + chunk : n;
+                        if (base + chunk >= n) exhausted = true;
                     }
                     const int avail = chunk_end > chunk_next ? chunk_end - chunk_next : 0;
                     const int rank = __popcll(idle & lt_mask);
@@ -924,8 +933,10 @@ static int g_trace_block_cap = 0;
 void rt_set_trace_block_cap(int cap) { g_trace_block_cap = cap; }
 // Persistent grid: one block per 256 rays up to the 1024 blocks that are resident at a time (4 per CU); blocks beyond those
 // only start when the queue is already empty.  (Fewer, longer-running blocks for small launches: +27 % time at 200x120.)
+static int g_small_rays_per_block = TRACE_BLOCK;
+void rt_set_small_rays_per_block(int v) { g_small_rays_per_block = v < 16 ? 16 : (v > TRACE_BLOCK ? TRACE_BLOCK : v); }
 static int trace_blocks(int n) {
-    int want = (n + TRACE_BLOCK - 1) / TRACE_BLOCK;
+    int want = (n + g_small_rays_per_block - 1) / g_small_rays_per_block;
     int cap = g_num_cus * TRACE_RESIDENT_PER_CU;
     if (g_trace_block_cap > 0 && g_trace_block_cap < cap) cap = g_trace_block_cap;
     return want < cap ? (want < 1 ? 1 : want) : cap;

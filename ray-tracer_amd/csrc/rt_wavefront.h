@@ -94,6 +94,7 @@ void rt_launch_shade_post(hipStream_t s, const DevScene &sc, const DevCamera &ca
 void rt_launch_backward(hipStream_t s, LevelBuf lv, int n, const int *n_dev, LevelBuf next, int has_next);
 void rt_launch_resolve(hipStream_t s, const DevCamera &cam, const int *pixel_list, int first_pixel, int n_pixels, LevelBuf lv0, int compact,
                        float *hdr, int *prim_id, float *prim_t);
+void rt_set_small_rays_per_block(int v);   // experiment hook: rays per block that size the grid of a launch smaller than the resident grid
 void rt_set_trace_block_cap(int cap);   // experiment hook: upper bound of the persistent grid (0 = default)
 void rt_set_num_cus(int n);      // compute units of the device (sizes the persistent grid)
 int rt_trace_grid_threads();     // most persistent threads a trace launch has (stride of the stack-overflow columns)
@@ -115,6 +116,16 @@ hipError_t rt_ply_scan_bytes(int64_t nf, size_t *bytes);
 hipError_t rt_ply_faces_mixed_count(hipStream_t s, const uint8_t *fb, const long long *offs, int64_t nf, int pre, int csize, int *ntri, int *tri_off, void *scan_tmp,
                                     size_t scan_bytes);
 hipError_t rt_ply_faces_mixed_write(hipStream_t s, const uint8_t *fb, const long long *offs, const int *tri_off, int64_t nf, int pre, int csize, int isize, int *out);
+// ascii bodies: line table, then per-line token scanners
+hipError_t rt_ply_ascii_scan_bytes(int64_t n_text, size_t *bytes);
+hipError_t rt_ply_ascii_lines(hipStream_t s, const uint8_t *text, int64_t n_text, int *flag, int *scan, void *scan_tmp, size_t scan_bytes, int64_t n_lines, long long *line_start);
+hipError_t rt_ply_ascii_vertices(hipStream_t s, const uint8_t *text, const long long *line_start, int64_t n_text, int64_t nv, const int tok[3], int is_double, float *out,
+                                 int *hard, int hard_cap, int *bad);
+hipError_t rt_ply_ascii_faces_count(hipStream_t s, const uint8_t *text, const long long *line_start, int64_t n_text, int64_t first_line, int64_t nf, int pre, int *ntri,
+                                    int *tri_off, void *scan_tmp, size_t scan_bytes, int *bad);
+hipError_t rt_ply_ascii_faces_write(hipStream_t s, const uint8_t *text, const long long *line_start, int64_t n_text, int64_t first_line, int64_t nf, int pre,
+                                    const int *tri_off, int *out, int *bad);
+hipError_t rt_ply_offset_copy(hipStream_t s, const int *src, int *dst, int64_t n, int offset);
 #define RT_TM_WORK_WORDS (4 + 2048)   // select state + histogram of rt_img_tonemap
 hipError_t rt_img_tonemap(hipStream_t s, const void *src, int from8, int64_t npx, float key, float burn_percent, float saturation,
                           float *lum, double *partial, unsigned *partial_max, unsigned *work, float *params, float *out);

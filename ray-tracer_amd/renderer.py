@@ -65,6 +65,7 @@ def library():
     L.rt_image_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, P(C.c_size_t), P(C.c_double)]
     L.rt_tonemap.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, P(abi.TonemapOpts), C.c_void_p, C.c_void_p, P(C.c_double)]
     L.rt_ply_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, P(abi.PlyLayout), C.c_void_p, C.c_void_p, P(C.c_int64), P(C.c_double)]
+    L.rt_ply_decode_to.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, P(abi.PlyLayout), C.c_void_p, C.c_void_p, C.c_int32, P(C.c_int64), P(C.c_double)]
     if L.rt_abi_version() != abi.RT_ABI_VERSION:
         raise RtError(abi.RT_ERR_ABI, "librt_mi355.so ABI %d != python mirror %d" % (L.rt_abi_version(), abi.RT_ABI_VERSION))
     _lib = L
@@ -108,7 +109,8 @@ def host_bvh(soup, gpu_device=None):
         info = abi.BvhInfo()
         L.rt_host_bvh_info(h, C.byref(info))
         se = np.zeros((info.n_leaves, 2), np.int64)
-        order = np.zeros(len(soup.prim_shape), np.int32)
+        n_prims = len(soup.prim_shape) if soup.prim_runs is None else int(sum(int(r["count"]) for r in soup.prim_runs))
+        order = np.zeros(n_prims, np.int32)
         boxes = np.zeros((info.n_leaves, 6), np.float32)
         dsc = np.zeros((info.n_leaves, 2), np.int64)
         dshape = np.zeros(info.n_leaf_prims, np.int32)
@@ -230,14 +232,26 @@ class Context:
         face record; layout: abi.PlyLayout filled from the header (scene.ply_layout)."""
         vb = np.frombuffer(vertex_bytes, np.uint8)
         fb = np.frombuffer(face_bytes, np.uint8)
+        fsize = len(vb) if layout.format == abi.RT_PLY_ASCII else len(fb)       # an ascii body is passed whole as vertex_bytes
         pos = np.empty((int(layout.n_vertices), 3), np.float32)
         tris = np.empty((2 * int(layout.n_faces), 3), np.int32)
         n = C.c_int64(0)
         ms = C.c_double(0)
-        self._check(self.L.rt_ply_decode(self.h, vb.ctypes.data if len(vb) else None, fb.ctypes.data if len(fb) else None, len(fb), C.byref(layout),
+        self._check(self.L.rt_ply_decode(self.h, vb.ctypes.data if len(vb) else None, fb.ctypes.data if len(fb) else None, fsize, C.byref(layout),
                                          pos.ctypes.data, tris.ctypes.data, C.byref(n), C.byref(ms) if timing else None))
         tris = tris[:n.value]
         return (pos, tris, ms.value) if timing else (pos, tris)
+
+    def decode_ply_to(self, vertex_bytes, face_bytes, layout, d_pos_ptr, d_tris_ptr, index_offset=0):
+        """rt_ply_decode_to: the same decoder with its output left in HBM (positions -> DEVICE float[nv*3] at d_pos_ptr,
+        triangles -> DEVICE int32[<= 2*nf*3] at d_tris_ptr with index_offset added).  Returns the number of triangles."""
+        vb = np.frombuffer(vertex_bytes, np.uint8)
+        fb = np.frombuffer(face_bytes, np.uint8)
+        fsize = len(vb) if layout.format == abi.RT_PLY_ASCII else len(fb)
+        n = C.c_int64(0)
+        self._check(self.L.rt_ply_decode_to(self.h, vb.ctypes.data if len(vb) else None, fb.ctypes.data if len(fb) else None, fsize, C.byref(layout),
+                                            d_pos_ptr, d_tris_ptr, int(index_offset), C.byref(n), None))
+        return int(n.value)
 
     def tonemap(self, hdr, key, burn_percent, saturation, gamma=2.2, input_8bit=True, nx=None, ny=None, timing=False):
         """Tonemapper::Tonemap (DefaultTonemapStrategy) on the device.  Returns (rgb float32 [ny, nx, 3], (average luminance,

@@ -104,6 +104,11 @@ class SceneSoup:
         self.lights = np.zeros((0,), abi.light_dtype)
         self.textures = np.zeros((0,), abi.texture_dtype)
         self.texels = np.zeros((0,), np.uint8)
+        # compact forms (rt_instance / rt_prim_run): a soup either carries them (the library expands them, on the device for large
+        # scenes) or is fully expanded (instances empty, prim_runs None)
+        self.instances = np.zeros((0,), abi.instance_dtype)
+        self.prim_runs = None
+        self.device_geometry = None             # (vert_pos ptr, vert_uv ptr, tri_vert ptr, tri_object ptr, n_vertices, n_triangles, keepalive)
         self.cameras = []                       # list of dicts (see camera_desc)
         self.tonemap = None                     # (key, burn percent, saturation, gamma) of Scene::tmo, or None
         self.name = ""
@@ -157,7 +162,40 @@ class SceneSoup:
         d.textures = self.textures.ctypes.data
         d.texels = self.texels.ctypes.data if len(self.texels) else None
         d.texels_bytes = len(self.texels)
+        self.instances = np.ascontiguousarray(self.instances, abi.instance_dtype)
+        d.n_instances = len(self.instances)
+        d.instances = self.instances.ctypes.data if len(self.instances) else None
+        if self.prim_runs is not None:
+            self.prim_runs = np.ascontiguousarray(self.prim_runs, abi.prim_run_dtype)
+            d.n_prim_runs = len(self.prim_runs)
+            d.prim_runs = self.prim_runs.ctypes.data
+            d.n_prims, d.prim_shape = 0, None
+        if self.device_geometry is not None:
+            g = self.device_geometry
+            d.vert_pos, d.vert_uv, d.tri_vert, d.tri_object, d.n_vertices, d.n_triangles = g[0], g[1], g[2], g[3], g[4], g[5]
+            d.geometry_on_device = 1
         return d
+
+    def expanded(self):
+        """The same scene with <MeshInstance> clones and primitive runs written out (what the reference's Scene holds after
+        parsing: Mesh::Clone, src/Mesh.cpp:126-180) — the form the CPU oracle takes."""
+        if len(self.instances) == 0 and self.prim_runs is None:
+            return self
+        assert self.device_geometry is None
+        import copy
+        e = copy.copy(self)
+        tv, to = [np.asarray(self.tri_vert, np.int32).reshape(-1, 3)], [np.asarray(self.tri_object, np.int32)]
+        for ins in self.instances:
+            a, n = int(ins["first_triangle"]), int(ins["n_triangles"])
+            tv.append(tv[0][a:a + n])
+            to.append(np.full(n, int(ins["object"]), np.int32))
+        e.tri_vert, e.tri_object = np.concatenate(tv), np.concatenate(to)
+        if self.prim_runs is not None:
+            e.prim_shape = np.concatenate([(np.arange(int(r["first"]), int(r["first"]) + int(r["count"]), dtype=np.int64) | int(r["flags"])).astype(np.int32)
+                                           for r in self.prim_runs]) if len(self.prim_runs) else np.zeros(0, np.int32)
+        e.instances, e.prim_runs = np.zeros((0,), abi.instance_dtype), None
+        e._contig()
+        return e
 
     def camera_desc(self, index=0, **override):
         c = dict(self.cameras[index])
@@ -251,7 +289,11 @@ class SceneSoup:
 # Incremental builder used by the XML loader and by the synthetic scenes
 # --------------------------------------------------------------------------------------------
 class SceneBuilder:
-    def __init__(self):
+    def __init__(self, compact=False):
+        """compact: <MeshInstance> clones and the primitive list are handed to the library as rt_instance / rt_prim_run records
+        (expanded there, on the device for large scenes) instead of being written out here."""
+        self.compact = bool(compact)
+        self._runs, self._inst, self._virtual = [], [], []
         self.soup = SceneSoup()
         self._vp, self._vuv = [], []
         self._tv, self._to = [], []
@@ -332,6 +374,9 @@ class SceneBuilder:
         return base
 
     def push_prims(self, tri_base, count, blurbox=False):
+        if self.compact:
+            self._runs.append((tri_base, count, abi.RT_PRIM_BLURBOX if blurbox else 0))
+            return
         ids = np.arange(tri_base, tri_base + count, dtype=np.int32)
         if blurbox:
             ids = ids | np.int32(abi.RT_PRIM_BLURBOX)
@@ -342,7 +387,10 @@ class SceneBuilder:
         obj = self.add_object(xform, abi.RT_OBJ_HAS_XFORM, material, tex_color, tex_normal)
         self._sph.append(np.array([center[0], center[1], center[2], radius], F32))
         self._so.append(obj)
-        self._prims.append(np.array([(len(self._sph) - 1) | abi.RT_PRIM_SPHERE], np.int32))
+        if self.compact:
+            self._runs.append((len(self._sph) - 1, 1, abi.RT_PRIM_SPHERE))
+        else:
+            self._prims.append(np.array([(len(self._sph) - 1) | abi.RT_PRIM_SPHERE], np.int32))
         return obj
 
     def add_triangle(self, p0, p1, p2, uv=None, material=0, tex_color=-1, tex_normal=-1):
@@ -366,7 +414,7 @@ class SceneBuilder:
         self.push_prims(tb, len(faces), blurbox=False)
         self.push_prims(tb, len(faces), blurbox=True)
         return {"obj": obj, "faces": faces.astype(np.int32), "xform": self._obj[obj]["xform"].reshape(4, 4).copy(),
-                "material": material, "tex_color": tex_color, "tex_normal": tex_normal}
+                "material": material, "tex_color": tex_color, "tex_normal": tex_normal, "tri_base": tb}
 
     def add_instance(self, base, xform=None, reset_transform=False, material=None, motion_blur=(0, 0, 0)):
         """<MeshInstance> (SceneParser.cpp:1075-1129, Mesh.cpp:126-180): clones share the base Vertex objects, the
@@ -377,7 +425,14 @@ class SceneBuilder:
         m = mat_mul(inst, base_m)                                  # Shape::SetTransformation, Shape.cpp:29-39
         mat = base["material"] if material is None else material
         obj = self.add_object(m, abi.RT_OBJ_HAS_XFORM | abi.RT_OBJ_COMPOSITE, mat, base["tex_color"], base["tex_normal"], motion_blur)
-        tb = self.add_triangles(base["faces"], obj)
+        if self.compact:
+            # the library clones the triangles (rt_instance): virtual triangle indices follow the explicit ones in instance order
+            assert "tri_base" in base, "instance of an instance: give the original mesh"
+            self._inst.append((base["tri_base"], len(base["faces"]), obj))
+            self._virtual.append(len(base["faces"]))
+            tb = ("virtual", len(self._inst) - 1)
+        else:
+            tb = self.add_triangles(base["faces"], obj)
         self.push_prims(tb, len(base["faces"]), blurbox=True)
         return {"obj": obj, "faces": base["faces"], "xform": m, "material": mat, "tex_color": base["tex_color"],
                 "tex_normal": base["tex_normal"]}
@@ -410,6 +465,12 @@ class SceneBuilder:
         s.sph_object = np.array(self._so, np.int32)
         s.objects = np.array(self._obj, abi.object_dtype) if self._obj else np.zeros(0, abi.object_dtype)
         s.prim_shape = cat(self._prims, (0,), np.int32)
+        if self.compact:
+            n_explicit = len(s.tri_vert)
+            vbase = np.concatenate([[0], np.cumsum(self._virtual)]).astype(np.int64) + n_explicit
+            runs = [((int(vbase[f[1]]) if isinstance(f, tuple) else int(f)), int(c), int(fl)) for f, c, fl in self._runs]
+            s.prim_runs = np.array([(a, c, fl, 0) for a, c, fl in runs], abi.prim_run_dtype) if runs else np.zeros(0, abi.prim_run_dtype)
+            s.instances = np.array([(a, n, o, 0) for a, n, o in self._inst], abi.instance_dtype) if self._inst else np.zeros(0, abi.instance_dtype)
         s.materials = np.array(self._mats, abi.material_dtype) if self._mats else np.zeros(0, abi.material_dtype)
         s.lights = np.array(self._lights, abi.light_dtype) if self._lights else np.zeros(0, abi.light_dtype)
         s.textures = np.array(self._tex, abi.texture_dtype) if self._tex else np.zeros(0, abi.texture_dtype)
@@ -453,20 +514,23 @@ def _ply_header(f):
     return fmt, elements
 
 
-def ply_layout(elements):
-    """abi.PlyLayout of a binary PLY body for rt_ply_decode, or None when the file needs the general reader (elements other
-    than vertex + face, list properties in the vertex element, more than one list in the face element, exotic types)."""
+def ply_layout(elements, ascii=False):
+    """abi.PlyLayout of a PLY body for rt_ply_decode, or None when the file needs the general reader (elements other
+    than vertex + face, list properties in the vertex element, more than one list in the face element, exotic types).
+    ascii: the body is text; offsets and sizes then count tokens instead of bytes."""
     if [e["name"] for e in elements] != ["vertex", "face"]:
         return None
     ve, fe = elements
     L = abi.PlyLayout()
     L.abi_version = abi.RT_ABI_VERSION
+    L.format = abi.RT_PLY_ASCII if ascii else abi.RT_PLY_BINARY_LE
+    size = (lambda t: 1) if ascii else (lambda t: np.dtype(_PLY_TYPES[t]).itemsize)
     off, where = 0, {}
     for p in ve["props"]:
         if p[0] == "list" or p[0] not in _PLY_TYPES:
             return None
         where[p[-1]] = (off, _PLY_TYPES[p[0]])
-        off += np.dtype(_PLY_TYPES[p[0]]).itemsize
+        off += size(p[0])
     if not all(k in where for k in "xyz") or len({where[k][1] for k in "xyz"}) != 1 or where["x"][1] not in ("f4", "f8"):
         return None
     L.pos_type = 1 if where["x"][1] == "f8" else 0
@@ -483,9 +547,9 @@ def ply_layout(elements):
         elif p[0] not in _PLY_TYPES:
             return None
         elif lst is None:
-            pre += np.dtype(_PLY_TYPES[p[0]]).itemsize
+            pre += size(p[0])
         else:
-            post += np.dtype(_PLY_TYPES[p[0]]).itemsize
+            post += size(p[0])
     if lst is None or lst[1] not in _PLY_TYPES or lst[2] not in _PLY_TYPES or _PLY_TYPES[lst[1]][0] == "f" or _PLY_TYPES[lst[2]][0] == "f":
         return None
     L.count_size, L.index_size = np.dtype(_PLY_TYPES[lst[1]]).itemsize, np.dtype(_PLY_TYPES[lst[2]]).itemsize
@@ -493,6 +557,26 @@ def ply_layout(elements):
         return None
     L.n_faces, L.face_pre_bytes, L.face_post_bytes = fe["count"], pre, post
     return L
+
+
+def _round_text_to_f32(vals64, token_of):
+    """float32 values of decimal tokens as a direct text -> float conversion gives them (a float property is extracted as a float
+    by happly, src/happly.h:2075-2095).  vals64: the tokens as correctly rounded doubles.  Rounding the double again is the same
+    except where the double lies exactly halfway between two floats or in the subnormal float range; those few are decided exactly."""
+    out = vals64.astype(F32)
+    bits = vals64.view(np.uint64)
+    mag = np.abs(vals64)
+    suspects = np.nonzero((((bits & np.uint64(0x1fffffff)) == np.uint64(0x10000000)) | ((mag < 1.1754943508222875e-38) & (mag > 0))))
+    if len(suspects[0]):
+        from fractions import Fraction
+        for i, k in zip(*suspects):
+            tok = token_of(int(i), int(k))
+            exact = Fraction(tok.decode() if isinstance(tok, bytes) else tok)
+            c = np.float32(vals64[i, k])
+            cands = [c, np.nextafter(c, np.float32(np.inf)), np.nextafter(c, np.float32(-np.inf))]
+            best = min(cands, key=lambda f: (abs(Fraction(float(f)) - exact), int(np.float32(f).view(np.uint32)) & 1))
+            out[i, k] = best
+    return out
 
 
 def _read_ply(path, decoder=None):
@@ -509,6 +593,11 @@ def _read_ply(path, decoder=None):
                 vbytes = int(L.n_vertices) * int(L.vertex_stride)
                 pos, tris = decoder(memoryview(body)[:vbytes], memoryview(body)[vbytes:], L)
                 return pos, tris.astype(np.int64)
+        if fmt == "ascii" and decoder is not None:
+            L = ply_layout(elements, ascii=True)
+            if L is not None:
+                pos, tris = decoder(memoryview(f.read()), b"", L)
+                return pos, tris.astype(np.int64)
         verts, faces = None, []
         quads_tris = None
         if fmt == "ascii":
@@ -519,14 +608,21 @@ def _read_ply(path, decoder=None):
                     n = len(el["props"])
                     names = [p[-1] for p in el["props"]]
                     arr = np.array(tokens[pos:pos + n * el["count"]], dtype=np.float64).reshape(el["count"], n)
+                    cols = [names.index("x"), names.index("y"), names.index("z")]
+                    verts = arr[:, cols]
+                    if all(tmap.get(el["props"][c][0]) == "f4" for c in cols):
+                        verts = _round_text_to_f32(verts, lambda i, k, pos=pos: tokens[pos + i * n + cols[k]])
                     pos += n * el["count"]
-                    verts = arr[:, [names.index("x"), names.index("y"), names.index("z")]]
                 elif el["name"] == "face":
                     for _ in range(el["count"]):
-                        k = int(tokens[pos])
-                        idx = [int(x) for x in tokens[pos + 1:pos + 1 + k]]
-                        pos += 1 + k
-                        faces.append(idx)
+                        for p in el["props"]:
+                            if p[0] != "list":
+                                pos += 1
+                                continue
+                            k = int(tokens[pos])
+                            if p[-1] in ("vertex_indices", "vertex_index"):
+                                faces.append([int(x) for x in tokens[pos + 1:pos + 1 + k]])
+                            pos += 1 + k
                 else:
                     for _ in range(el["count"]):
                         for p in el["props"]:

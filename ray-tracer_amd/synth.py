@@ -73,10 +73,12 @@ def dragon_standin_scene(n_tris=1_000_000, nx=800, ny=480, seed=7):
     return b.finish("dragon_standin_%d" % n_tris)
 
 
-def instanced_scene(n_instances=50, n_tris=1_000_000, nx=3840, ny=2160, spp=256, seed=7, perlin_table=None, checker=None):
+def instanced_scene(n_instances=50, n_tris=1_000_000, nx=3840, ny=2160, spp=256, seed=7, perlin_table=None, checker=None, compact=False):
     """BASELINE.json config 5: a grid of MeshInstances of the stand-in mesh with distinct rotations,
-    half of them with a Perlin bump_normal texture, on a floor with a replace_kd image texture."""
-    b = SceneBuilder()
+    half of them with a Perlin bump_normal texture, on a floor with a replace_kd image texture.  compact: the instances and
+    the primitive list go to the library as rt_instance / rt_prim_run records (52 M triangles are then never written out on
+    the host)."""
+    b = SceneBuilder(compact=compact)
     s = b.soup
     s.max_depth = 6
     s.ambient = np.array([25, 25, 25], F32)

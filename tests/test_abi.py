@@ -29,7 +29,8 @@ def test_struct_sizes_match(rt):
     L, abi = rt.library(), rt.abi
     expect = [abi.material_dtype.itemsize, abi.light_dtype.itemsize, abi.texture_dtype.itemsize, abi.object_dtype.itemsize,
               C.sizeof(abi.SceneDesc), C.sizeof(abi.CameraDesc), C.sizeof(abi.RenderOpts), C.sizeof(abi.Stats), abi.ray_dtype.itemsize,
-              abi.hit_dtype.itemsize, C.sizeof(abi.BvhInfo), C.sizeof(abi.TonemapOpts), C.sizeof(abi.PlyLayout)]
+              abi.hit_dtype.itemsize, C.sizeof(abi.BvhInfo), C.sizeof(abi.TonemapOpts), C.sizeof(abi.PlyLayout), abi.instance_dtype.itemsize,
+              abi.prim_run_dtype.itemsize]
     assert [L.rt_abi_sizeof(i) for i in range(len(expect))] == expect
     assert L.rt_abi_sizeof(99) == -1
     assert L.rt_abi_version() == abi.RT_ABI_VERSION
