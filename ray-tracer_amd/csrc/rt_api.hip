@@ -219,6 +219,9 @@ static void apply_tuning_knobs(rt_ctx *c) {
     const DevSceneParams &d = c->host.params;
     p.tri_min_lanes = d.tri_min_lanes; p.donate = d.donate; p.refill_min_idle = d.refill_min_idle; p.donate_min_idle = d.donate_min_idle;
     p.prune_err = d.prune_err; p.prune_rel = d.prune_rel; p.cone_off = 0; p.min_chunk = d.min_chunk;
+    p.interleave_shift = d.interleave_shift; p.interleave_max_share = d.interleave_max_share;
+    if (const char *ig = getenv("RT_INTERLEAVE_SHIFT")) p.interleave_shift = clampi(atoi(ig), 0, 6);
+    if (const char *im = getenv("RT_INTERLEAVE_MAX_SHARE")) p.interleave_max_share = clampi(atoi(im), 0, 1 << 30);
     rt_set_trace_block_cap(0);
     if (const char *mc = getenv("RT_MIN_CHUNK")) p.min_chunk = clampi(atoi(mc), 1, 64);
     if (const char *sb = getenv("RT_SMALL_RAYS_PER_BLOCK")) rt_set_small_rays_per_block(atoi(sb));

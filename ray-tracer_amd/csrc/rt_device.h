@@ -77,7 +77,7 @@ struct DevVertex {            // 32 bytes: what the winner's finalisation reads
 };
 static_assert(sizeof(DevVertex) == 32, "DevVertex must be 32 bytes");
 
-#define RT_TRI_MIN_LANES 16      // run the primitive path of the traversal once this many lanes of a wave wait in a leaf
+#define RT_TRI_MIN_LANES 10      // run the primitive path of the traversal once this many lanes of a wave wait in a leaf (4 ... 12 within 0.5 %, 16: +1 %, 24: +6 %)
 #define RT_DONATE_MIN_IDLE 32    // once the queue is empty: split the rays in flight (donation) when this many lanes of a wave are idle (28-36 measured best)
 #define RT_REFILL_MIN_IDLE 16    // retire + refill (or donate) once this many lanes of a wave are idle (8 ... 48 swept: 16 best)
 
@@ -107,6 +107,8 @@ struct DevSceneParams {
                               // the register allocator spills and reloads (with a wait for every outstanding load) once per node step
     int32_t min_chunk;        // smallest number of rays a wave of the traversal reserves at a time (small launches)
     int32_t cone_off;         // tuning builds only (RT_NO_CONE): prune far children without the normal-cone test (NOT exact)
+    int32_t interleave_shift; // log2 of the run of consecutive queue entries a wave takes from one place (6: the whole chunk, no interleaving)
+    int32_t interleave_max_share;  // interleave only launches with at most this many rays per wave of the grid
 };
 #define RT_NO_ROOT 0x7fffffff
 

@@ -401,10 +401,17 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
     // of 64 to the first waves and none to the rest: the launch then lasts as long as its longest ray, and the idle lanes of
     // every wave can start taking over parts of its long rays (donation) at once.
     int chunk = TRACE_CHUNK;
+    // Queue positions -> ray indices.  Neighbouring rays are about equally long, so a launch with only a few rays per lane ends
+    // when the wave that drew the longest 64 neighbours ends.  Such launches are interleaved: position 64 c + q (chunk c, slot q)
+    // is ray (q >> s) * (C << s) + (c << s) + (q & (2^s - 1)) with C chunks in all, so that a wave draws 64 >> s runs of 2^s
+    // neighbours from places evenly spread over the queue, every wave gets the same mix, and the idle lanes of a wave take over
+    // parts of its long rays.  npos: positions to hand out (a multiple of 64 when interleaved; positions beyond n are empty).
+    int il_shift = 6, il_chunks = 0, npos = n;
     {
         const int waves = gridDim.x * (TRACE_BLOCK / 64);
         const int share = (n + waves - 1) / waves;
         if (share < TRACE_CHUNK) chunk = share < sc.p.min_chunk ? sc.p.min_chunk : share;
+        if (sc.p.interleave_shift < 6 && share <= sc.p.interleave_max_share) { il_shift = sc.p.interleave_shift; il_chunks = (n + 63) >> 6; npos = il_chunks << 6; }
     }
     // work donation (see the retire block): a lane may hand the bottom entry of its stack to an idle lane of the wave
     int sbase = 0;                   // the stack is [sbase, sp): entries below sbase were given away
@@ -477,16 +484,20 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                         if (lane == 0) base = atomicAdd(fetch_counter, chunk);
                         base = __shfl(base, 0);
                         chunk_next = base;
-                        chunk_end = base + chunk < n ? base + chunk : n;
-                        if (base + chunk >= n) exhausted = true;
+                        chunk_end = base + chunk < npos ? base + chunk : npos;
+                        if (base + chunk >= npos) exhausted = true;
                     }
                     const int avail = chunk_end > chunk_next ? chunk_end - chunk_next : 0;
                     const int rank = __popcll(idle & lt_mask);
                     if (COUNT) { ++dbg.v[2]; if (!has_ray && rank < avail) ++dbg.v[3]; }
                     if (!has_ray && rank < avail) {
-                        const int mine = chunk_next + rank;
+                        int mine = chunk_next + rank;
+                        if (il_shift < 6) {
+                            const int q = mine & 63;
+                            mine = (((q >> il_shift) * il_chunks + (mine >> 6)) << il_shift) + (q & ((1 << il_shift) - 1));
+                        }
                         f3 d;
-                        if (io.load(mine, o, d, time)) {
+                        if (mine < n && io.load(mine, o, d, time)) {
                             payi[PAY_RAY_IDX * TRACE_BLOCK] = mine; payi[PAY_PENDING * TRACE_BLOCK] = 0;
                             pay[PAY_DY * TRACE_BLOCK] = d.y; pay[PAY_DZ * TRACE_BLOCK] = d.z; pay[PAY_DLEN * TRACE_BLOCK] = norm3(d);
                             dirx = d.x;
