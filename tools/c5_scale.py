@@ -13,8 +13,10 @@ rt = importlib.import_module("ray-tracer_amd")
 synth = importlib.import_module("ray-tracer_amd.synth")
 ni, nx, ny, spp = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((1, 10), (2, 1920), (3, 1080), (4, 1)))
 t0 = time.time()
-soup = synth.instanced_scene(ni, 1_000_000, nx, ny, spp, perlin_table=rt.renderer.perlin_tables(1)[0])
-print("scene: %d triangles, %d primitive references, built in %.1f s" % (len(soup.tri_vert), len(soup.prim_shape), time.time() - t0), flush=True)
+compact = bool(os.environ.get("C5_COMPACT"))        # instances and primitive runs instead of written-out clones: the library expands them in HBM
+soup = synth.instanced_scene(ni, 1_000_000, nx, ny, spp, perlin_table=rt.renderer.perlin_tables(1)[0], compact=compact)
+print("scene: %d explicit triangles, %d instances, %d primitive references / runs, described in %.1f s" % (
+    len(soup.tri_vert), len(soup.instances), len(soup.prim_runs) if soup.prim_runs is not None else len(soup.prim_shape), time.time() - t0), flush=True)
 ctx = rt.Context(0)
 t0 = time.time()
 ctx.upload(soup)
