@@ -29,7 +29,8 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 RAY_BYTES = 32                 # closest-hit query: origin+time, direction+medium read (2 x 16 B)
 HIT_BYTES = 32                 # closest-hit query: raw hit record written (2 x 16 B)
 SHADOW_BYTES = 52              # shadow query: origin, direction+distance, shaded point+slot read (3 x 16 B), 4 B result written
-NODE_BYTES = 112               # node step: the 7 x 16 B of a DevNode4 the step reads (four child boxes + references)
+NODE_BYTES = 112               # node step: 7 x 16 B of a DevNode4 (four child boxes + references); the eighth piece a step also loads, the four
+                               # cone words of the exactness rule, is not counted as algorithmic
 PRIM_BYTES = 48                # the 3 x 16 B of a DevPrim a triangle / sphere test reads (geometry, object, kind)
 RES_BY_GPUS = {1: (800, 480), 2: (1600, 480), 4: (1600, 960), 8: (3200, 960)}
 TILE = 32
