@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel (default: 1 = config 2 as quoted; 16 with --scaling strong)")
     ap.add_argument("--eighth-share", action="store_true",
                     help="also time the share one GPU of eight gets of this frame (every 8th tile); off by default so that the default run launches only whole frames")
+    ap.add_argument("--broadcast-scene", action="store_true",
+                    help="N > 1: rank 0 builds the scene and the other ranks receive its arenas over RCCL (rt_scene_export / rt_scene_import) instead of building their own")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-step", type=int, default=1, help="CPU baseline renders every k-th row of the frame")
     args = ap.parse_args()
@@ -84,12 +86,17 @@ def main():
     if spp != 1:
         soup.cameras[0]["num_samples"] = spp
     ctx = rt.Context(local_rank)
+    mg = importlib.import_module("ray-tracer_amd.multigpu")
     t0 = time.time()
-    ctx.upload(soup)
+    if args.broadcast_scene and world > 1:
+        if rank == 0:
+            ctx.upload(soup)
+        mg.broadcast_scene(ctx, dist, rank, 0, dev, torch, soup=soup)
+    else:
+        ctx.upload(soup)                            # default: every rank builds its own copy, in parallel
     upload_s = time.time() - t0
     cd = soup.camera_desc(0)
 
-    mg = importlib.import_module("ray-tracer_amd.multigpu")
     tg = mg.TileGather(nx, ny, TILE, rank, world, dev, torch)                    # compact owned pixels + frame, HBM resident
 
     def step(opts, stats):

@@ -400,6 +400,23 @@ int rt_ply_decode(rt_ctx *ctx, const void *vertex_bytes, const void *face_bytes,
 int rt_ply_decode_to(rt_ctx *ctx, const void *vertex_bytes, const void *face_bytes, size_t face_bytes_size, const rt_ply_layout *layout,
                      float *d_out_pos, int32_t *d_out_tris, int32_t index_offset, int64_t *out_n_tris, double *ms_kernels);
 
+/* ---- one build, many GPUs: the uploaded scene as a header + flat arenas ----------------------------------------------------
+ * The reference holds one Scene and one BVHTree that all its worker threads read (DefaultRenderer.cpp:29-33, 65-75); with one
+ * process per GPU every rank either builds its own copy (rt_scene_upload on every rank, the default) or one rank builds and the
+ * others receive the result: the arenas hold indices only, no pointers, so their bytes are valid on any GPU.
+ *   rt_scene_header_bytes()                 size of the opaque header (a few hundred bytes: parameters, counts, tree statistics)
+ *   rt_scene_export(ctx, header, bytes)     fills the header and the byte size of each of the RT_SCENE_ARENAS arenas
+ *   rt_scene_export_arena(ctx, i, dst)      copies arena i to dst (device memory of any GPU of the process, or host memory)
+ *   rt_scene_import(ctx, header, arenas)    makes ctx hold that scene: arenas[i] = bytes[i] bytes received from the exporting
+ *                                           rank (device or host memory; the library copies them into arenas of its own)
+ * The transport in between is the caller's (ncclBroadcast / torch.distributed.broadcast of byte buffers).  A header of another
+ * library build (different ABI version or record sizes) is rejected with RT_ERR_ABI. */
+#define RT_SCENE_ARENAS 12
+size_t rt_scene_header_bytes(void);
+int rt_scene_export(rt_ctx *ctx, void *header, uint64_t arena_bytes[RT_SCENE_ARENAS]);
+int rt_scene_export_arena(rt_ctx *ctx, int index, void *dst);
+int rt_scene_import(rt_ctx *ctx, const void *header, const void *const arenas[RT_SCENE_ARENAS]);
+
 /* Host-only view of the BVH that rt_scene_upload would build (reference topology, BVHTree.cpp:39-153), so that tests
  * can compare it with an independent build without a GPU.  Leaves are listed in left-to-right DFS order.
  *   leaf_start_end      [2*n_leaves]  range of each leaf in the reference's re-ordered primitive array

@@ -121,6 +121,7 @@ class PlyLayout(C.Structure):
 
 
 RT_PLY_BINARY_LE, RT_PLY_ASCII = 0, 1
+RT_SCENE_ARENAS = 12
 
 
 class BvhInfo(C.Structure):

@@ -156,6 +156,7 @@ struct rt_ctx {
     DevArray<rt_light> d_lights;
     DevArray<rt_texture> d_textures;
     DevArray<uint8_t> d_texels;
+    uint64_t arena_bytes[RT_SCENE_ARENAS] = {0};   // bytes in use of the twelve arrays above, in that order (rt_scene_export)
     // wavefront state
     std::vector<StreamLane> lanes;
     hipEvent_t ev_ready = nullptr;
@@ -341,6 +342,111 @@ int rt_scene_upload(rt_ctx *c, const rt_scene_desc *scene) {
     d.tri_vert = c->d_tri_vert.p; d.materials = c->d_materials.p; d.lights = c->d_lights.p; d.textures = c->d_textures.p; d.texels = c->d_texels.p;
     // traversal stack overflow area: entries beyond the LDS part, one column per persistent thread
     c->overflow_depth = std::max(0, h.params.stack_bound + 2 - rt_trace_lds_stack_depth());
+    HIP_TRY(c, c->d_overflow.ensure((size_t)std::max(1, c->overflow_depth) * rt_trace_grid_threads()));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    {
+        const bool dev_tree = gs.prims != nullptr, dev_shapes = gs.verts != nullptr;
+        uint64_t *b = c->arena_bytes;
+        b[0] = (dev_tree ? (uint64_t)gs.n_wide : h.nodes.size()) * sizeof(DevNode4);
+        b[1] = (dev_tree ? (uint64_t)gs.n_nodes : h.chain.size()) * sizeof(DevChain);
+        b[2] = (dev_tree ? (gs.node_chain ? 4 * (uint64_t)gs.n_wide : 0) : h.node_chain.size()) * sizeof(int32_t);
+        b[3] = (dev_tree ? (uint64_t)gs.n_leaves : h.leaves.size()) * sizeof(DevLeaf);
+        b[4] = (dev_tree ? (uint64_t)gs.n_leaf_prims : h.prims.size()) * sizeof(DevPrim);
+        b[5] = h.objects.size() * sizeof(DevObject);
+        b[6] = (dev_shapes ? (uint64_t)gs.n_verts : h.verts.size()) * sizeof(DevVertex);
+        b[7] = (dev_shapes ? 3 * (uint64_t)gs.n_tris : h.tri_vert.size()) * sizeof(int32_t);
+        b[8] = h.materials.size() * sizeof(rt_material);
+        b[9] = h.lights.size() * sizeof(rt_light);
+        b[10] = h.textures.size() * sizeof(rt_texture);
+        b[11] = h.texels.size();
+    }
+    c->has_scene = true;
+    return RT_OK;
+}
+
+// ---- the uploaded scene as a header + flat arenas (one build, many GPUs) ---------------------------------------------------
+namespace {
+struct SceneHeader {
+    uint32_t magic, abi_version;
+    uint32_t record_bytes[RT_SCENE_ARENAS];      // element size of every arena: a library with other record layouts must refuse the bytes
+    uint64_t arena_bytes[RT_SCENE_ARENAS];
+    rt_bvh_info info;
+    DevSceneParams params;
+};
+const uint32_t kSceneMagic = 0x4e435352u;        // "RSCN"
+const uint32_t kRecordBytes[RT_SCENE_ARENAS] = {sizeof(DevNode4), sizeof(DevChain), sizeof(int32_t), sizeof(DevLeaf), sizeof(DevPrim), sizeof(DevObject),
+                                                sizeof(DevVertex), sizeof(int32_t), sizeof(rt_material), sizeof(rt_light), sizeof(rt_texture), 1};
+void *arena_ptr(rt_ctx *c, int i) {
+    void *p[RT_SCENE_ARENAS] = {c->d_nodes.p, c->d_chain.p, c->d_node_chain.p, c->d_leaves.p, c->d_prims.p, c->d_objects.p,
+                                c->d_verts.p, c->d_tri_vert.p, c->d_materials.p, c->d_lights.p, c->d_textures.p, c->d_texels.p};
+    return p[i];
+}
+}  // namespace
+
+size_t rt_scene_header_bytes(void) { return sizeof(SceneHeader); }
+
+int rt_scene_export(rt_ctx *c, void *header, uint64_t arena_bytes[RT_SCENE_ARENAS]) {
+    if (!c || !header || !arena_bytes) return RT_ERR_INVALID;
+    if (!c->has_scene) { c->error = "rt_scene_export: no scene uploaded"; return RT_ERR_NO_SCENE; }
+    SceneHeader hd;
+    std::memset(&hd, 0, sizeof(hd));
+    hd.magic = kSceneMagic; hd.abi_version = RT_ABI_VERSION;
+    for (int i = 0; i < RT_SCENE_ARENAS; ++i) { hd.record_bytes[i] = kRecordBytes[i]; hd.arena_bytes[i] = c->arena_bytes[i]; arena_bytes[i] = c->arena_bytes[i]; }
+    hd.info = c->host.info;
+    hd.params = c->host.params;
+    std::memcpy(header, &hd, sizeof(hd));
+    return RT_OK;
+}
+
+int rt_scene_export_arena(rt_ctx *c, int index, void *dst) {
+    if (!c || index < 0 || index >= RT_SCENE_ARENAS) return RT_ERR_INVALID;
+    if (!c->has_scene) { c->error = "rt_scene_export_arena: no scene uploaded"; return RT_ERR_NO_SCENE; }
+    if (c->arena_bytes[index] == 0) return RT_OK;
+    if (!dst) { c->error = "rt_scene_export_arena: dst is NULL"; return RT_ERR_INVALID; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(dst, arena_ptr(c, index), c->arena_bytes[index], hipMemcpyDefault, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_scene_import(rt_ctx *c, const void *header, const void *const arenas[RT_SCENE_ARENAS]) {
+    if (!c || !header || !arenas) return RT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    SceneHeader hd;
+    std::memcpy(&hd, header, sizeof(hd));
+    if (hd.magic != kSceneMagic) { c->error = "rt_scene_import: not a scene header"; return RT_ERR_INVALID; }
+    if (hd.abi_version != RT_ABI_VERSION) { c->error = "rt_scene_import: header of another ABI version"; return RT_ERR_ABI; }
+    for (int i = 0; i < RT_SCENE_ARENAS; ++i) {
+        if (hd.record_bytes[i] != kRecordBytes[i]) { c->error = "rt_scene_import: header of a library with other record layouts"; return RT_ERR_ABI; }
+        if (hd.arena_bytes[i] % kRecordBytes[i] != 0 || (hd.arena_bytes[i] && !arenas[i])) { c->error = "rt_scene_import: bad arena size or NULL arena"; return RT_ERR_INVALID; }
+    }
+    // what the kernels index with must be consistent with the arena sizes (the bytes come from another process)
+    const DevSceneParams &p = hd.params;
+    const uint64_t n_wide = hd.arena_bytes[0] / sizeof(DevNode4), n_prims = hd.arena_bytes[4] / sizeof(DevPrim);
+    if (p.n_lights < 0 || (uint64_t)p.n_lights * sizeof(rt_light) != hd.arena_bytes[9] || p.n_materials < 0 || (uint64_t)p.n_materials * sizeof(rt_material) != hd.arena_bytes[8] ||
+        p.n_textures < 0 || (uint64_t)p.n_textures * sizeof(rt_texture) != hd.arena_bytes[10] || p.n_objects < 0 || (uint64_t)p.n_objects * sizeof(DevObject) != hd.arena_bytes[5] ||
+        (p.root != RT_NO_ROOT && p.root >= 0 && (uint64_t)p.root >= n_wide) || hd.arena_bytes[2] != 4 * n_wide * sizeof(int32_t) || (p.root != RT_NO_ROOT && n_prims == 0) ||
+        p.stack_bound < 0 || p.stack_bound > (1 << 20) || p.bg_texture >= p.n_textures) { c->error = "rt_scene_import: header inconsistent with its arenas"; return RT_ERR_INVALID; }
+    c->has_scene = false;
+    c->level_ratio.clear();
+    c->host = HostScene();
+    c->host.info = hd.info;
+    c->host.params = hd.params;
+#define RT_IMPORT(idx, darr)                                                                                                 \
+    do {                                                                                                                     \
+        const size_t n_el = (size_t)(hd.arena_bytes[idx] / kRecordBytes[idx]);                                               \
+        HIP_TRY(c, (darr).ensure(n_el ? n_el : 1));                                                                          \
+        if (n_el) HIP_TRY(c, hipMemcpyAsync((darr).p, arenas[idx], hd.arena_bytes[idx], hipMemcpyDefault, c->stream));       \
+        c->arena_bytes[idx] = hd.arena_bytes[idx];                                                                           \
+    } while (0)
+    RT_IMPORT(0, c->d_nodes); RT_IMPORT(1, c->d_chain); RT_IMPORT(2, c->d_node_chain); RT_IMPORT(3, c->d_leaves); RT_IMPORT(4, c->d_prims); RT_IMPORT(5, c->d_objects);
+    RT_IMPORT(6, c->d_verts); RT_IMPORT(7, c->d_tri_vert); RT_IMPORT(8, c->d_materials); RT_IMPORT(9, c->d_lights); RT_IMPORT(10, c->d_textures); RT_IMPORT(11, c->d_texels);
+#undef RT_IMPORT
+    DevScene &d = c->dev;
+    d.p = hd.params;
+    d.nodes = c->d_nodes.p; d.chain = c->d_chain.p; d.node_chain = c->d_node_chain.p; d.leaves = c->d_leaves.p; d.prims = c->d_prims.p; d.objects = c->d_objects.p; d.verts = c->d_verts.p;
+    d.tri_vert = c->d_tri_vert.p; d.materials = c->d_materials.p; d.lights = c->d_lights.p; d.textures = c->d_textures.p; d.texels = c->d_texels.p;
+    c->overflow_depth = std::max(0, hd.params.stack_bound + 2 - rt_trace_lds_stack_depth());
     HIP_TRY(c, c->d_overflow.ensure((size_t)std::max(1, c->overflow_depth) * rt_trace_grid_threads()));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->has_scene = true;

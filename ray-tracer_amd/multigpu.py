@@ -67,3 +67,38 @@ class TileGather:
         elif self.rank == 0:
             self.frame.index_copy_(0, self.orders[0], src[:self.counts[0]])
         return self.frame
+
+
+def broadcast_scene(ctx, dist, rank, src, device, torch, host_staging=False, soup=None):
+    """One build, many GPUs: rank `src` has uploaded (built) the scene in `ctx`; every other rank receives the header and the flat
+    arenas over the process group and adopts them (rt_scene_export / rt_scene_import) instead of building its own copy.  With the nccl
+    backend the arenas travel GPU to GPU (RCCL broadcast over xGMI); host_staging=True is for groups that only take CPU tensors (gloo).
+    The default remains one build per rank (DESIGN: every rank has its own PCIe link and the builds run in parallel); this is for hosts
+    where the description cannot be read on every rank, or where the host link is the bottleneck."""
+    n_arenas = renderer.abi.RT_SCENE_ARENAS
+    tdev = torch.device("cpu") if host_staging else device
+    hdr_bytes = int(renderer.library().rt_scene_header_bytes())
+    meta = torch.zeros(hdr_bytes + 8 * n_arenas, dtype=torch.uint8)
+    if rank == src:
+        hdr, sizes = ctx.export_scene_header()
+        meta[:hdr_bytes] = torch.from_numpy(hdr)
+        meta[hdr_bytes:] = torch.from_numpy(np.array(sizes, np.uint64).view(np.uint8))
+    meta_t = meta.to(tdev)
+    dist.broadcast(meta_t, src=src)
+    meta = meta_t.cpu()                                           # synchronous
+    sizes = [int(x) for x in meta[hdr_bytes:].numpy().view(np.uint64)]
+    bufs = []
+    for i, nbytes in enumerate(sizes):
+        buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=tdev)
+        if rank == src and nbytes:
+            ctx.export_scene_arena(i, buf.data_ptr())             # device -> device (or -> host when staging); returns when the copy is done
+        if nbytes:
+            if not host_staging:
+                torch.cuda.synchronize(device)
+            dist.broadcast(buf, src=src)
+        bufs.append(buf)
+    if rank != src:
+        if not host_staging:
+            torch.cuda.synchronize(device)
+        ctx.import_scene(meta[:hdr_bytes].numpy(), [b.data_ptr() if n else 0 for b, n in zip(bufs, sizes)], soup=soup)
+    return sizes

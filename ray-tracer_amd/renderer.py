@@ -65,6 +65,10 @@ def library():
     L.rt_image_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, P(C.c_size_t), P(C.c_double)]
     L.rt_tonemap.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, P(abi.TonemapOpts), C.c_void_p, C.c_void_p, P(C.c_double)]
     L.rt_ply_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, P(abi.PlyLayout), C.c_void_p, C.c_void_p, P(C.c_int64), P(C.c_double)]
+    L.rt_scene_header_bytes.restype = C.c_size_t
+    L.rt_scene_export.argtypes = [C.c_void_p, C.c_void_p, P(C.c_uint64)]
+    L.rt_scene_export_arena.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.rt_scene_import.argtypes = [C.c_void_p, C.c_void_p, P(C.c_void_p)]
     L.rt_ply_decode_to.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, P(abi.PlyLayout), C.c_void_p, C.c_void_p, C.c_int32, P(C.c_int64), P(C.c_double)]
     if L.rt_abi_version() != abi.RT_ABI_VERSION:
         raise RtError(abi.RT_ERR_ABI, "librt_mi355.so ABI %d != python mirror %d" % (L.rt_abi_version(), abi.RT_ABI_VERSION))
@@ -156,6 +160,27 @@ class Context:
     def upload(self, soup):
         d = soup.desc()
         self._check(self.L.rt_scene_upload(self.h, C.byref(d)))
+        self.soup = soup
+        return self
+
+    # ---- one build, many GPUs (rt_scene_export / rt_scene_import) --------------------------------------------------
+    def export_scene_header(self):
+        """(header bytes, [byte size of each arena]) of the uploaded scene."""
+        hdr = np.zeros(self.L.rt_scene_header_bytes(), np.uint8)
+        sizes = (C.c_uint64 * abi.RT_SCENE_ARENAS)()
+        self._check(self.L.rt_scene_export(self.h, hdr.ctypes.data, sizes))
+        return hdr, [int(x) for x in sizes]
+
+    def export_scene_arena(self, index, dst_ptr):
+        """Copies arena `index` to dst_ptr (device or host memory of at least that arena's size)."""
+        self._check(self.L.rt_scene_export_arena(self.h, int(index), dst_ptr))
+
+    def import_scene(self, header, arena_ptrs, soup=None):
+        """Adopts a scene exported by another context / rank: header as exported, arena_ptrs = device or host addresses of the
+        received bytes (0 for an empty arena).  `soup` (cameras etc.) is kept for render(cam=index)."""
+        hdr = np.ascontiguousarray(header, np.uint8)
+        ptrs = (C.c_void_p * abi.RT_SCENE_ARENAS)(*[C.c_void_p(int(p) or None) for p in arena_ptrs])
+        self._check(self.L.rt_scene_import(self.h, hdr.ctypes.data, ptrs))
         self.soup = soup
         return self
 

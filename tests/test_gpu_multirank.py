@@ -66,3 +66,57 @@ def test_two_ranks_render_and_gather(tmp_path):
                           "--master-port", "29541", str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "MULTIRANK_OK" in out.stdout
+
+
+BCAST_WORKER = textwrap.dedent('''
+    import importlib, os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    rt = importlib.import_module("ray-tracer_amd")
+    mg = importlib.import_module("ray-tracer_amd.multigpu")
+    synth = importlib.import_module("ray-tracer_amd.synth")
+    nx, ny, tile = 320, 192, 32
+    soup = synth.dragon_standin_scene(60000, nx, ny)          # every rank knows the cameras; only rank 0 builds the scene
+    ctx = rt.Context(0)
+    if rank == 0:
+        ctx.upload(soup)
+    sizes = mg.broadcast_scene(ctx, dist, rank, 0, dev, torch, host_staging=True, soup=soup)
+    assert sum(sizes) > 10_000_000 and len(sizes) == rt.abi.RT_SCENE_ARENAS
+    info = ctx.bvh_info()
+    cd = soup.camera_desc(0)
+    tg = mg.TileGather(nx, ny, tile, rank, world, dev, torch, host_staging=True)
+    opts = ctx.make_opts(seed=0, tile_size=tile, tile_rank=rank, tile_world=world, output_on_device=True, compact_output=True)
+    buf = tg.acquire()
+    buf.zero_()
+    torch.cuda.synchronize()
+    ctx.render_device(cd, opts, buf.data_ptr())
+    frame = tg.gather(dist)
+    nodes = torch.tensor([int(info.n_nodes)], dtype=torch.int64)
+    both = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(both, nodes)
+    if rank == 0:
+        assert int(both[0][0]) == int(both[1][0]) > 0
+        full, fid, ft, fst = ctx.render(0)
+        got = frame.numpy().reshape(ny, nx, 3)
+        assert np.array_equal(got.view(np.uint32), full.view(np.uint32)), "frame of (built tiles + imported tiles) differs from the single-rank frame"
+        print("BROADCAST_OK", int(both[0][0]), sum(sizes))
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+''')
+
+
+def test_scene_built_once_and_broadcast(tmp_path):
+    """Rank 0 builds the scene, rank 1 receives header + arenas (rt_scene_export / rt_scene_import through multigpu.broadcast_scene,
+    gloo with host staging here, RCCL on device buffers on a multi-GPU node) and renders its tiles without ever calling rt_scene_upload."""
+    script = tmp_path / "bworker.py"
+    script.write_text(BCAST_WORKER % (ROOT, ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29543", str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "BROADCAST_OK" in out.stdout
