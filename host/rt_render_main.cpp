@@ -1,7 +1,8 @@
 // rt_render — the reference's main (src/main.cpp:15-30) over the MI355X path, in the reference's language:
 //   parse the scene (here: the flat scene file, host/scene_file.h), create the renderer, RenderSceneIntoPPM, report the time.
-// usage: rt_render <scene.rtscene> [out_dir] [--rays <rays.bin> <hits.bin>]
+// usage: rt_render <scene.rtscene> [out_dir] [--rays <rays.bin> <hits.bin>] [--shared-scene]
 //   --rays: also answer a batch of AccelerationStructure::Intersect queries (rt_ray records in, rt_hit records out).
+//   --shared-scene: the accelerator of --rays adopts the scene the renderer has built (rt_scene_export / rt_scene_import) instead of building it again.
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -17,8 +18,10 @@ int main(int argc, char **argv) {
         rt_mi355::LoadScene(argv[1], scene);
         std::string out_dir = ".";
         const char *rays_path = nullptr, *hits_path = nullptr;
+        bool shared_scene = false;
         for (int i = 2; i < argc; ++i) {
             if (!std::strcmp(argv[i], "--rays") && i + 2 < argc) { rays_path = argv[i + 1]; hits_path = argv[i + 2]; i += 2; }
+            else if (!std::strcmp(argv[i], "--shared-scene")) shared_scene = true;
             else out_dir = argv[i];
         }
         rt_mi355::Mi355Renderer renderer(0, out_dir);                   // main.cpp:20  new DefaultRenderer()
@@ -38,8 +41,13 @@ int main(int argc, char **argv) {
             if (std::fread(rays.data(), sizeof(rt_ray), rays.size(), f) != rays.size()) { std::fclose(f); throw rt_mi355::Error(RT_ERR_INVALID, "short read"); }
             std::fclose(f);
             std::vector<rt_hit> hits(rays.size());
-            rt_mi355::Mi355Accelerator accel(scene.view);                 // AccelerationStructureFactory::CreateAccelerationStructure
-            accel.Intersect(rays.data(), rays.size(), hits.data());
+            if (shared_scene) {
+                rt_mi355::Mi355Accelerator accel(renderer.context().ExportScene());
+                accel.Intersect(rays.data(), rays.size(), hits.data());
+            } else {
+                rt_mi355::Mi355Accelerator accel(scene.view);             // AccelerationStructureFactory::CreateAccelerationStructure
+                accel.Intersect(rays.data(), rays.size(), hits.data());
+            }
             f = std::fopen(hits_path, "wb");
             if (!f || std::fwrite(hits.data(), sizeof(rt_hit), hits.size(), f) != hits.size()) throw rt_mi355::Error(RT_ERR_INVALID, std::string("cannot write ") + hits_path);
             std::fclose(f);

@@ -84,6 +84,35 @@ public:
         Check(rt_ply_decode(h_, vertex_bytes, face_bytes, face_bytes_size, &layout, pos.data(), tris.data(), &n, nullptr));
         tris.resize((size_t)n * 3);
     }
+    // the same decoder with its output left in DEVICE buffers of the caller (d_pos [nv*3] floats, d_tris [<= 2*nf*3] ints, vertex
+    // indices + index_offset); returns the number of triangles.  With rt_scene_desc.geometry_on_device the mesh never visits the host.
+    int64_t DecodePlyTo(const void *vertex_bytes, const void *face_bytes, size_t face_bytes_size, rt_ply_layout layout, float *d_pos, int32_t *d_tris,
+                        int32_t index_offset = 0) {
+        layout.abi_version = RT_ABI_VERSION;
+        int64_t n = 0;
+        Check(rt_ply_decode_to(h_, vertex_bytes, face_bytes, face_bytes_size, &layout, d_pos, d_tris, index_offset, &n, nullptr));
+        return n;
+    }
+    // One build, many GPUs: the uploaded scene as an opaque header + RT_SCENE_ARENAS byte arrays (host copies here; a multi-GPU host
+    // passes device buffers to rt_scene_export_arena / rt_scene_import directly and moves them with its own broadcast).
+    struct SceneBytes { std::vector<unsigned char> header; std::vector<std::vector<unsigned char> > arenas; };
+    SceneBytes ExportScene() {
+        SceneBytes b;
+        b.header.resize(rt_scene_header_bytes());
+        uint64_t sizes[RT_SCENE_ARENAS];
+        Check(rt_scene_export(h_, b.header.data(), sizes));
+        b.arenas.resize(RT_SCENE_ARENAS);
+        for (int i = 0; i < RT_SCENE_ARENAS; ++i) {
+            b.arenas[i].resize((size_t)sizes[i]);
+            if (sizes[i]) Check(rt_scene_export_arena(h_, i, b.arenas[i].data()));
+        }
+        return b;
+    }
+    void ImportScene(const SceneBytes &b) {
+        const void *ptrs[RT_SCENE_ARENAS];
+        for (int i = 0; i < RT_SCENE_ARENAS; ++i) ptrs[i] = (i < (int)b.arenas.size() && !b.arenas[i].empty()) ? b.arenas[i].data() : nullptr;
+        Check(rt_scene_import(h_, b.header.data(), ptrs));
+    }
     rt_ctx *handle() const { return h_; }
 
 private:
@@ -96,6 +125,8 @@ private:
 class Mi355Accelerator {
 public:
     explicit Mi355Accelerator(const SceneView &scene, int hip_device = 0) : ctx_(hip_device) { ctx_.Upload(scene.desc); }
+    // from a scene another context has already built (the reference's renderer and accelerator share one BVHTree, DefaultRenderer.cpp:29-33)
+    explicit Mi355Accelerator(const Context::SceneBytes &built, int hip_device = 0) : ctx_(hip_device) { ctx_.ImportScene(built); }
     void Intersect(const rt_ray *rays, size_t n, rt_hit *out) const { ctx_.Intersect(rays, n, out); }
     void Intersect(const rt_ray &ray, rt_hit &out) const { ctx_.Intersect(&ray, 1, &out); }      // drop-in form: one launch per ray
 private:

@@ -53,7 +53,8 @@ def test_cpp_host_equals_python_mirror(rt, scene_path, tmp_path, name):
     rays.tofile(str(tmp_path / "rays.bin"))
     cdir, pdir = tmp_path / "cpp", tmp_path / "py"
     cdir.mkdir(), pdir.mkdir()
-    out = _run([str(tmp_path / "s.rtscene"), str(cdir), "--rays", str(tmp_path / "rays.bin"), str(tmp_path / "hits.bin")])
+    extra = ["--shared-scene"] if name == "scienceTree" else []      # the accelerator adopts the renderer's scene instead of building it again
+    out = _run([str(tmp_path / "s.rtscene"), str(cdir), "--rays", str(tmp_path / "rays.bin"), str(tmp_path / "hits.bin")] + extra)
     assert out.returncode == 0, out.stderr
     r = rt.Mi355Renderer(0, out_dir=str(pdir))
     r.RenderSceneIntoPPM(soup)
