@@ -15,10 +15,11 @@
 //
 // Per subtree the builder therefore keeps a cone of (unoriented) triangle normals in WORLD space and the smallest
 // edge-angle sine s of its triangles; a child of a wide node carries both packed into 32 bits:
-//     bits  0..10, 11..21   cone axis, octahedral encoding
-//     bits 22..31           k: the subtree may be pruned by distance iff |axis_decoded . d| >= (k / 1022) * |d|
-// k is rounded up from sin(half-angle + asin(rho_min / s) + decoding error) * |axis_decoded|; k = 1023 never allows it
-// (wide cones, slivers), k = 0 always does (a subtree of spheres only: their test is a well-conditioned quadratic).
+//     bits  0..7, 8..15, 16..23   cone axis: three integer components in [-127, 127], stored + 127 (largest component = +-127)
+//     bits 24..31                 k: the subtree may be pruned by distance iff |axis_int . d| >= k * (220 / 255) * |d|
+// k is rounded up from sin(half-angle + asin(rho_min / s) + what the integer axis loses) * |axis_int|; k = 255 never allows it
+// (|axis_int| < 220: wide cones, slivers), k = 0 always does (a subtree of spheres only: their test is a well-conditioned quadratic).
+// The test is evaluated for every far child of every node step, so the word is made to decode in three byte conversions.
 // An object transform M = [A | t] maps object-space normals by inverse(transpose(A)); the object-space conditioning is at least
 // |m_w . d_w| / |d_w| with m_w = (sigma_min(A)^2 / sigma_max(A)) * inverse(transpose(A)) * (s * n_obj), which also covers the
 // growth of the object-space error on its way back to world space (DevObject::cone_k holds the factor).
@@ -29,9 +30,10 @@
 
 #define RT_CONE_RHO_MIN 1e-2f
 #define RT_CONE_FULL_ALPHA 1.5f        // half-angles from here on never allow pruning (alpha + asin(rho/s) must stay below pi/2)
-#define RT_CONE_NEVER 1023u
-#define RT_CONE_WORD_NEVER (RT_CONE_NEVER << 22)
+#define RT_CONE_NEVER 255u
+#define RT_CONE_WORD_NEVER ((RT_CONE_NEVER << 24) | 0x7f7f7fu)
 #define RT_CONE_WORD_ALWAYS 0u
+#define RT_CONE_K_SCALE (220.0f / 255.0f)
 
 struct NCone {
     f3 a;            // unit axis (sign irrelevant: normals are lines)
@@ -95,53 +97,45 @@ RT_HD NCone cone_merge(const NCone &A, const NCone &B0) {
 }
 
 // ---- packing ---------------------------------------------------------------------------------------------------------
-// axis as the decoder reconstructs it (L1 norm 1, not normalised)
+// axis as the decoder reconstructs it (integer components, not normalised)
 RT_HD f3 cone_axis_decode(unsigned w) {
-    float x = (float)(w & 2047u) * (2.0f / 2047.0f) - 1.0f;
-    float y = (float)((w >> 11) & 2047u) * (2.0f / 2047.0f) - 1.0f;
-    const float z = 1.0f - fabsf(x) - fabsf(y);
-    const float t = z < 0.0f ? -z : 0.0f;
-    x += x >= 0.0f ? -t : t;
-    y += y >= 0.0f ? -t : t;
-    return mk3(x, y, z);
+    return mk3((float)(w & 255u) - 127.0f, (float)((w >> 8) & 255u) - 127.0f, (float)((w >> 16) & 255u) - 127.0f);
 }
 // May a subtree with cone word w be pruned by distance for a ray of direction d (|d| = dlen)?
 RT_HD bool cone_allows_prune(unsigned w, float dx, float dy, float dz, float dlen) {
     const f3 a = cone_axis_decode(w);
-    const float thr = (float)(w >> 22) * (1.0f / 1022.0f);
-    return fabsf(a.x * dx + a.y * dy + a.z * dz) >= thr * dlen;
+    const float dot = fmaf(a.x, dx, fmaf(a.y, dy, a.z * dz));
+    return fabsf(dot) >= (float)(w >> 24) * (RT_CONE_K_SCALE * dlen);
 }
 RT_HD unsigned cone_pack(const NCone &c) {
     if (c.alpha < 0.0f) return RT_CONE_WORD_ALWAYS;
     if (cone_is_full(c)) return RT_CONE_WORD_NEVER;
     const float q = RT_CONE_RHO_MIN / c.smin;
     if (!(q < 1.0f)) return RT_CONE_WORD_NEVER;
-    // octahedral projection of the axis
-    const float l1 = fabsf(c.a.x) + fabsf(c.a.y) + fabsf(c.a.z);
-    if (!(l1 > 0.0f)) return RT_CONE_WORD_NEVER;
-    float px = c.a.x / l1, py = c.a.y / l1;
-    if (c.a.z < 0.0f) {
-        const float ox = px, oy = py;
-        px = (1.0f - fabsf(oy)) * (ox >= 0.0f ? 1.0f : -1.0f);
-        py = (1.0f - fabsf(ox)) * (oy >= 0.0f ? 1.0f : -1.0f);
+    const float ax = fabsf(c.a.x), ay = fabsf(c.a.y), az = fabsf(c.a.z);
+    const float m = ax > ay ? (ax > az ? ax : az) : (ay > az ? ay : az);
+    if (!(m > 0.0f) || !(m < 3.0e38f)) return RT_CONE_WORD_NEVER;
+    float comp[3] = {c.a.x / m * 127.0f, c.a.y / m * 127.0f, c.a.z / m * 127.0f};
+    unsigned uv = 0;
+    for (int i = 0; i < 3; ++i) {
+        float r = floorf(comp[i] + 0.5f);
+        r = r < -127.0f ? -127.0f : (r > 127.0f ? 127.0f : r);
+        if (!(r == r)) return RT_CONE_WORD_NEVER;
+        uv |= (unsigned)(int)(r + 127.0f) << (8 * i);
     }
-    float fu = (px * 0.5f + 0.5f) * 2047.0f + 0.5f, fv = (py * 0.5f + 0.5f) * 2047.0f + 0.5f;
-    fu = fu < 0.0f ? 0.0f : (fu > 2047.0f ? 2047.0f : fu);
-    fv = fv < 0.0f ? 0.0f : (fv > 2047.0f ? 2047.0f : fv);
-    const unsigned u = (unsigned)fu, v = (unsigned)fv;
-    const unsigned uv = u | (v << 11);
     const f3 ad = cone_axis_decode(uv);
     const float lad = norm3(ad);
     if (!(lad > 0.0f)) return RT_CONE_WORD_NEVER;
     f3 an = ad / lad;
     if (dot3(an, c.a) < 0.0f) an = -an;
-    const float delta = cone_angle(an, c.a);                  // what the 11-bit axis loses
+    const float delta = cone_angle(an, c.a);                  // what the integer axis loses
     const float beta = c.alpha + asinf(q) + delta + 1e-4f;
     if (!(beta < 1.55f)) return RT_CONE_WORD_NEVER;
-    const float thr = sinf(beta) * lad * 1.00001f + 1e-5f;
-    const float fk = ceilf(thr * 1022.0f);
-    if (!(fk < 1023.0f)) return RT_CONE_WORD_NEVER;
-    return uv | ((unsigned)fk << 22);
+    // the decoder's dot product carries three roundings of terms up to 220 |d| (about 4e-5 |d|): the 1e-3 covers them
+    const float thr = sinf(beta) * lad * 1.00001f + 1e-3f;
+    const float fk = ceilf(thr / RT_CONE_K_SCALE);
+    if (!(fk < 255.0f)) return RT_CONE_WORD_NEVER;
+    return uv | ((unsigned)fk << 24);
 }
 
 #endif

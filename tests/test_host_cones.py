@@ -108,9 +108,12 @@ def test_cone_word_basics():
     L = rtp.library()
     d = np.array([0.3, -0.5, 0.8], np.float32)
     assert L.rt_cone_allows_prune(0, d.ctypes.data) == 1                 # k = 0: always
-    assert L.rt_cone_allows_prune(1023 << 22, d.ctypes.data) == 0       # k = 1023: never
+    assert L.rt_cone_allows_prune(255 << 24 | 0x7f7f7f, d.ctypes.data) == 0       # k = 255: never
     for ax in np.eye(3, dtype=np.float32):
-        assert L.rt_cone_allows_prune(1023 << 22 | 1023 | 1023 << 11, ax.ctypes.data) == 0
+        for axis_bytes in (0x7f7f7f, 0xfefefe, 0x000000, 0xfe7f7f, 0x7ffe00):      # whatever the axis: |axis| < 220
+            assert L.rt_cone_allows_prune(255 << 24 | axis_bytes, ax.ctypes.data) == 0
+    diag = (np.ones(3) / np.sqrt(3)).astype(np.float32)
+    assert L.rt_cone_allows_prune(255 << 24 | 0xfefefe, diag.ctypes.data) == 0      # the longest axis against the direction along it
     # a flat quad (two coplanar triangles, normal +z): prunable for a ray 5 degrees off the plane, not for one 0.2 degrees off it
     b = rtp.SceneBuilder()
     m = b.add_material()
