@@ -633,7 +633,7 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
         return RT_OK;
     };
 
-    // counters of one batch: [child counts | fetch counters | - | shadow queue lengths], (max_depth + 2) ints each
+    // counters of one batch: [child counts | fetch counters | refraction children | shadow queue lengths], (max_depth + 2) ints each
     auto shadow_view = [&](StreamLane &ln, int *counts, int k) -> ShadowBuf {
         StreamLane::ShadowMem &m = ln.sh[k & 1];
         ShadowBuf sb;
@@ -691,7 +691,7 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
             }
             nxv = nx.view();
         } else { nxv = nx.view(); nxv.capacity = next_cap; }     // buffers were sized before the batch started
-        rt_launch_shade_pre(st, c->dev, dc, lm.view(), n, ndev(k), shadow_view(ln, counts, k), nxv, k, counts + k + 1);
+        rt_launch_shade_pre(st, c->dev, dc, lm.view(), n, ndev(k), shadow_view(ln, counts, k), nxv, k, counts + k + 1, counts + 2 * (max_depth + 2) + k);
         if (!dev && k < max_depth) {
             HIP_TRY(c, hipMemcpyAsync(ln.h_count, counts + k + 1, sizeof(int), hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipEventRecord(ln.ev_count, st));
@@ -699,7 +699,8 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
         // the ray statistics of level k and the lighting of level k-1 (which needs only this launch's shadow results) are queued
         // AFTER the count copy: they keep the GPU busy while the host makes its round trip for the child count (measured gap
         // without them: 21-27 us per level)
-        if (stats) rt_launch_count_kinds(st, lm.view(), n, ndev(k), shadow_view(ln, counts, k), c->d_kind.p);
+        // host-counted frames only: frames whose lengths stay on the device get the rays per kind from the level counters afterwards
+        if (stats && !dev) rt_launch_count_kinds(st, lm.view(), n, ndev(k), shadow_view(ln, counts, k), c->d_kind.p);
         if (k > 0) rt_launch_shade_post(st, c->dev, dc, ln.levels[k - 1].view(), ln.levels[k - 1].count, ndev(k - 1), sb_prev);
         return RT_OK;
     };
@@ -716,6 +717,8 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
     // of this scene; lengths stay on the device; a level that outgrows its queue drops the excess children and the pass
     // returns 1 (the caller then renders the frame again, host-counted).
     uint64_t level_syncs = 0, frame_passes = 0;
+    uint64_t kinds_host[RT_RAY_KINDS] = {0, 0, 0, 0};   // rays per kind of a frame whose level lengths stayed on the device
+    bool kinds_on_host = false;
     // the context stream continues after every batch stream has drained; the end of the frame's kernels for the timing
     auto drain_lanes = [&]() -> hipError_t {
         for (int j = 0; j < n_streams; ++j) {
@@ -727,6 +730,8 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
     };
     auto run_frame = [&](bool predicted) -> int {
         ++frame_passes;
+        kinds_on_host = predicted;
+        std::fill(kinds_host, kinds_host + RT_RAY_KINDS, (uint64_t)0);
         HIP_TRY(c, hipMemsetAsync(c->d_kind.p, 0, RT_RAY_KINDS * sizeof(unsigned long long), s));
         if (d_counters) {
             HIP_TRY(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(DevCounters), s));
@@ -807,6 +812,13 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
                 trace_rays += (uint64_t)r.n0;
                 for (int k = 1; k <= max_depth; ++k) trace_rays += (uint64_t)std::max(0, hc[k]);
                 for (int k = 0; k <= max_depth; ++k) trace_rays += (uint64_t)std::max(0, hc[3 * (max_depth + 2) + k]);
+                // rays per kind: a level's children are its refraction + reflection rays, its shadow queue its shadow rays
+                for (int k = 0; k <= max_depth; ++k) {
+                    const uint64_t refr = (uint64_t)std::max(0, hc[2 * (max_depth + 2) + k]), kids = (uint64_t)std::max(0, hc[k + 1]);
+                    kinds_host[RT_RAY_REFRACT] += refr;
+                    kinds_host[RT_RAY_REFLECT] += kids > refr ? kids - refr : 0;
+                    kinds_host[RT_RAY_SHADOW] += (uint64_t)std::max(0, hc[3 * (max_depth + 2) + k]);
+                }
             }
             return overflow ? 1 : RT_OK;
         }
@@ -895,6 +907,7 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         stats->rays[RT_RAY_PRIMARY] = primary_rays;
+        if (kinds_on_host) for (int q = 0; q < RT_RAY_KINDS; ++q) kinds[q] = kinds_host[q];
         stats->rays[RT_RAY_SHADOW] = kinds[RT_RAY_SHADOW]; stats->rays[RT_RAY_REFLECT] = kinds[RT_RAY_REFLECT]; stats->rays[RT_RAY_REFRACT] = kinds[RT_RAY_REFRACT];
         stats->node_visits = hc.node_visits; stats->box_tests = hc.box_tests; stats->tri_tests = hc.tri_tests; stats->sphere_tests = hc.sphere_tests;
         if (getenv("RT_TRACE_DEBUG")) {

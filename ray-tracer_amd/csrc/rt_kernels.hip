@@ -1315,7 +1315,7 @@ __device__ __forceinline__ bool replaces_all(const DevScene &sc, const DevObject
 // here).  The plain instantiation carries neither code path (and not their registers: 2x the occupancy).
 template <bool NTEX, bool RNG>
 __global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, LevelBuf lv, int n, const int *n_dev, ShadowBuf sb, LevelBuf next, int depth,
-                                                   int *next_count) {
+                                                   int *next_count, int *refr_count) {
     // Queue space is reserved once per 256-thread block (two atomics per block: same-address atomics from every wave cost
     // ~6 ns each, chip-wide serial).  Inactive threads of the last block take part in the barriers with lit = false, no children.
     __shared__ int s_lit[4], s_child[4], s_refl[4], s_base[2];
@@ -1461,6 +1461,8 @@ __global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, L
         // counting, so the host sees count > capacity afterwards and renders the batch again with exact sizes.
         if (cb + block_child > next.capacity) cb = -1;
         s_base[1] = cb;
+        // how many of the children are refraction rays (the host splits the level's length into rays per kind with it)
+        if (block_refr && cb >= 0 && refr_count) atomicAdd(refr_count, block_refr);
     }
     __syncthreads();
     if (s_base[1] < 0) { has_refr = false; has_refl = false; }
@@ -1522,14 +1524,14 @@ __global__ __launch_bounds__(256) void k_count_kinds(LevelBuf lv, int n, const i
     }
 }
 void rt_launch_shade_pre(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, const int *n_dev, ShadowBuf sb, LevelBuf next, int depth,
-                         int *next_count) {
+                         int *next_count, int *refr_count) {
     if (n <= 0) return;
     const dim3 g((n + 255) / 256), b(256);
     const bool ntex = sc.p.has_normal_tex != 0, rng = sc.p.has_rng != 0;
-    if (ntex && rng) hipLaunchKernelGGL((k_shade_pre<true, true>), g, b, 0, s, sc, cam, lv, n, n_dev, sb, next, depth, next_count);
-    else if (ntex) hipLaunchKernelGGL((k_shade_pre<true, false>), g, b, 0, s, sc, cam, lv, n, n_dev, sb, next, depth, next_count);
-    else if (rng) hipLaunchKernelGGL((k_shade_pre<false, true>), g, b, 0, s, sc, cam, lv, n, n_dev, sb, next, depth, next_count);
-    else hipLaunchKernelGGL((k_shade_pre<false, false>), g, b, 0, s, sc, cam, lv, n, n_dev, sb, next, depth, next_count);
+    if (ntex && rng) hipLaunchKernelGGL((k_shade_pre<true, true>), g, b, 0, s, sc, cam, lv, n, n_dev, sb, next, depth, next_count, refr_count);
+    else if (ntex) hipLaunchKernelGGL((k_shade_pre<true, false>), g, b, 0, s, sc, cam, lv, n, n_dev, sb, next, depth, next_count, refr_count);
+    else if (rng) hipLaunchKernelGGL((k_shade_pre<false, true>), g, b, 0, s, sc, cam, lv, n, n_dev, sb, next, depth, next_count, refr_count);
+    else hipLaunchKernelGGL((k_shade_pre<false, false>), g, b, 0, s, sc, cam, lv, n, n_dev, sb, next, depth, next_count, refr_count);
 }
 // rays per kind of a level after its surface pass (statistics only; a launch of its own so that the host can queue it behind
 // the copy of the child count)

@@ -88,7 +88,7 @@ int rt_trace_block_threads();    // threads per block of the trace kernels
 int rt_trace_resident_blocks();  // blocks of the trace kernels resident on the device at a time (the grid cap)
 // next.capacity bounds the children written: a block whose children do not fit writes none, *next_count still counts them
 void rt_launch_shade_pre(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, const int *n_dev, ShadowBuf sb, LevelBuf next, int depth,
-                         int *next_count);
+                         int *next_count, int *refr_count);
 void rt_launch_count_kinds(hipStream_t s, LevelBuf lv, int n, const int *n_dev, ShadowBuf sb, unsigned long long *ray_kind_counts);
 void rt_launch_shade_post(hipStream_t s, const DevScene &sc, const DevCamera &cam, LevelBuf lv, int n, const int *n_dev, ShadowBuf sb);
 void rt_launch_backward(hipStream_t s, LevelBuf lv, int n, const int *n_dev, LevelBuf next, int has_next);
