@@ -182,6 +182,7 @@ def test_frames_after_the_first_make_no_host_round_trip(rt, orc, gpu_ctx, scene_
     # several batches per frame on two streams, still without a round trip
     h3, i3, _, s3 = gpu_ctx.render(0, nx=200, ny=200, max_batch_samples=6000, num_streams=2)
     assert s3.level_syncs == 0 and s3.frame_passes == 1 and np.array_equal(h3.view(np.uint32), h1.view(np.uint32))
+    assert list(s3.rays) == list(s1.rays)                  # rays per kind (refraction rays included) from the level counters of every batch
     # a camera that sees nothing: almost no secondary rays ...
     cd = soup.camera_desc(0, nx=200, ny=200)
     away = type(cd).from_buffer_copy(cd)
@@ -197,4 +198,5 @@ def test_frames_after_the_first_make_no_host_round_trip(rt, orc, gpu_ctx, scene_
     assert s6.level_syncs == 0 and s6.frame_passes == 1 and np.array_equal(h6.view(np.uint32), h1.view(np.uint32))
     c_hdr, c_id, c_t, c_st = orc.OracleScene(soup).render(0, nthreads=8, nx=200, ny=200)
     compare_frames(h6, c_hdr, i1, c_id, t1, c_t)
+    assert list(s6.rays) == list(c_st.rays) and s6.rays[rt.abi.RT_RAY_REFRACT] > 0
     assert list(s6.rays) == list(c_st.rays)
