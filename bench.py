@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: the resolution grows with N (each GPU keeps config 2's 800x480 share); strong: one fixed frame (800x480 at --spp samples) cut over the N GPUs")
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel (default: 1 = config 2 as quoted; 16 with --scaling strong)")
+    ap.add_argument("--workload", choices=["config2", "config5"], default="config2",
+                    help="config2: the headline workload; config5: BASELINE config 5's geometry (50 instances of the 1M-triangle mesh, 3840x2160), one fixed frame: implies --scaling strong")
+    ap.add_argument("--instances", type=int, default=50, help="mesh instances of --workload config5")
     ap.add_argument("--eighth-share", action="store_true",
                     help="also time the share one GPU of eight gets of this frame (every 8th tile); off by default so that the default run launches only whole frames")
     ap.add_argument("--broadcast-scene", action="store_true",
@@ -79,12 +82,21 @@ def main():
     synth = importlib.import_module("ray-tracer_amd.synth")
     abi = rt.abi
 
+    c5 = args.workload == "config5"
+    if c5:
+        args.scaling = "strong"
     strong = args.scaling == "strong"
-    spp = args.spp if args.spp > 0 else (16 if strong else 1)
-    nx, ny = resolution_for(1 if strong else world)
-    soup = synth.dragon_standin_scene(args.tris, nx, ny)
-    if spp != 1:
-        soup.cameras[0]["num_samples"] = spp
+    spp = args.spp if args.spp > 0 else (1 if c5 else (16 if strong else 1))
+    if c5:
+        # instances and primitive runs go to the library in compact form and are expanded in HBM (52 M triangles at the defaults)
+        nx, ny = 3840, 2160
+        soup = synth.instanced_scene(args.instances, args.tris, nx, ny, spp, perlin_table=rt.renderer.perlin_tables(1)[0], compact=True)
+        args.no_cpu_baseline = True               # the CPU restatement needs minutes for this scene
+    else:
+        nx, ny = resolution_for(1 if strong else world)
+        soup = synth.dragon_standin_scene(args.tris, nx, ny)
+        if spp != 1:
+            soup.cameras[0]["num_samples"] = spp
     ctx = rt.Context(local_rank)
     mg = importlib.import_module("ray-tracer_amd.multigpu")
     t0 = time.time()
@@ -160,7 +172,7 @@ def main():
     # exactly this library (the file records its SHA-256) and for this workload; otherwise null
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath) and world == 1 and spp == 1 and args.tris == 1_000_000:
+    if os.path.exists(tpath) and world == 1 and spp == 1 and args.tris == 1_000_000 and not c5:
         try:
             import hashlib
             tj = json.load(open(tpath))
@@ -173,7 +185,7 @@ def main():
     survey = None
     cpath = os.path.join(ROOT, "tests", "golden", "canonical_counts.json")
     ckey = "config2 dragon_standin_%d %dx%d" % (args.tris, nx, ny)
-    if os.path.exists(cpath) and spp == 1:
+    if os.path.exists(cpath) and spp == 1 and not c5:
         try:
             cc = json.load(open(cpath)).get(ckey)
             if cc and cc["rays"] == int(n_rays) and world == 1:
@@ -235,8 +247,10 @@ def main():
     out = {"metric": "Mrays/s (primary+secondary, whole node)", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "BASELINE config 2: other_dragon.xml camera/lights/materials, depth 6, %d spp, stand-in %d-triangle mesh "
-                                  "(dragon_remeshed.ply is a missing blob) + mirror floor" % (spp, args.tris),
+           "config": {"workload": ("BASELINE config 5 geometry: %d instances of the stand-in %d-triangle mesh (half with Perlin bump), textured floor, depth 6, %d spp"
+                                   % (args.instances, args.tris, spp)) if c5 else
+                                  ("BASELINE config 2: other_dragon.xml camera/lights/materials, depth 6, %d spp, stand-in %d-triangle mesh "
+                                   "(dragon_remeshed.ply is a missing blob) + mirror floor" % (spp, args.tris)),
                       "resolution": [nx, ny], "spp": spp, "rays_per_frame": int(total_rays), "tiles": "%dx%d interleaved over %d GPU(s)" % (TILE, TILE, world),
                       "bvh_nodes": int(bvh.n_nodes), "bvh_depth": int(bvh.max_depth), "scene_upload_s": round(upload_s, 2), "kernels_ms_per_frame": round(sum(s.ms_kernels for s in st_steps) / args.steps, 4),
                       "host_round_trips_per_frame": int(st_steps[-1].level_syncs), "traversal": "exact (normal-cone pruning rule): hit ids equal the reference's unpruned traversal",
