@@ -625,7 +625,10 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
         }
         float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0, q6 = q0, q7 = q0;
         const float4 *rec = nodes4 + 8 * (size_t)(at_node ? cur : 0);
-        if (at_node) { q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3]; q4 = rec[4]; q5 = rec[5]; q6 = rec[6]; q7 = rec[7]; }
+        // the cone words (q7) only matter to a lane that can prune by distance, i.e. one that has a bound when the loads go out; a bound
+        // found by this iteration's primitive test prunes from the next node step on (what loads the vector memory path is lanes x loads)
+        const bool can_prune = bound < sc.p.flt_max;
+        if (at_node) { q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3]; q4 = rec[4]; q5 = rec[5]; q6 = rec[6]; if (can_prune) q7 = rec[7]; }
         // keeps the compiler from testing the primitive's kind (and waiting for it) before the node loads above are issued
         asm volatile("" : "+v"(p_kind), "+v"(p_obj) : : "memory");
         if (COUNT) { ++dbg.v[4]; if (at_node) ++dbg.v[5]; if (do_tri) ++dbg.v[7]; if (run_tri) ++dbg.v[6]; }
@@ -680,7 +683,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                 // The child's box begins beyond the best hit (an undecided box never does).  It is skipped only if no triangle
                 // below it is so nearly in a plane with the ray that the reference's Cramer solve could put a "hit" anywhere
                 // on the ray (rt_cone.h) — decided after this loop, for the lanes that have such a child.
-                far[i] = c == 1 && lb > bound;
+                far[i] = c == 1 && can_prune && lb > bound;
                 any_far = any_far || far[i];
                 // An undecided LEAF is decided exactly by the chain walk.  An undecided INTERNAL child of an ordinary ray (grazing
                 // its box) is simply entered: boxes nest, so that is conservative and cheap.  A ray with a zero direction component

@@ -1,5 +1,6 @@
 """Writes profiles/<round>_bench_kernel_stats.md, profiles/<round>_pmc_trace_kernel.md and profiles/traffic_latest.json from the
-outputs of tools/profile_round.sh <tag> (merged back under gpurun_out/).  usage: python tools/profile_docs.py <tag> <round>"""
+outputs of tools/profile_round.sh <tag> (merged back under gpurun_out/).  Optional: the directory tag of tools/pmc_extra.sh and a file with a
+later default bench line of the same library.  usage: python tools/profile_docs.py <tag> <round> [<extra_pmc_tag> [<bench_json>]]"""
 import os
 import subprocess
 import sys
@@ -76,4 +77,35 @@ scalar instructions and one memory round trip per iteration, 4 waves per SIMD at
 """ % (rnd[1:], tag, blk.strip(), d["cyc"], d["valu"], d["vb"], d["lanes"], d["act"], d["wait"], d["waiti"], d["l2"], d["acc"], d["accr"], d["ta"], d["tas"],
        d["fetch"], 2 * d["fetch"], d["write"], d["per_launch"]))
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "traffic_json.py"), os.path.join(G, tag + "_pmc"), "2"])
+if len(sys.argv) > 3:
+    xs = open(os.path.join(G, sys.argv[3] + "_summary.txt")).read()
+    xb = xs[xs.index("== k_trace\n"):]
+    xb = xb[:xb.index("\n==", 3)] if "\n==" in xb[3:] else xb
+    x = {}
+    for l in xb.splitlines():
+        q = l.split()
+        if len(q) >= 2 and q[1].isdigit():
+            x[q[0]] = int(q[1])
+    open(os.path.join(ROOT, "profiles", rnd + "_pmc_trace_kernel.md"), "a").write("""
+## Two more passes: instruction fetch, instruction cache, LDS, scalar unit (tools/pmc_extra.sh, same driver and library)
+
+```
+%s
+```
+
+Per frame: %.2f G instruction fetches, instruction-cache misses %.0f k (the 18 KB loop stays resident), LDS bank conflicts %.1f M cycles against
+%.0f M cycles of LDS activity, waves waiting for the LDS %.1f %% of their cycles, scalar instructions %.2f G (%.2f per VALU instruction).
+No unit is saturated: VALU %.0f %%, texture addresser %.0f %%, scalar and LDS far below; together with the footprint-independent time per
+node step this is what "bound by the per-wave serial chain at four waves per SIMD" rests on.
+""" % (xb.strip(), x["SQ_IFETCH"] / frames / 1e9, x["SQC_ICACHE_MISSES"] / frames / 1e3, x["SQ_LDS_BANK_CONFLICT"] / frames / 1e6, x["SQ_LDS_IDX_ACTIVE"] / frames / 1e6,
+       100.0 * x["SQ_WAIT_INST_LDS"] / c["SQ_WAVE_CYCLES"], x["SQ_INST_CYCLES_SALU"] / frames / 1e9, x["SQ_INST_CYCLES_SALU"] / c["SQ_INSTS_VALU"], d["vb"], d["ta"]))
+if len(sys.argv) > 4:
+    later = open(sys.argv[4]).read().strip().splitlines()[-1]
+    open(os.path.join(ROOT, "profiles", rnd + "_bench_kernel_stats.md"), "a").write("""
+A later default run of the same library (`roofline.traffic` now filled from profiles/traffic_latest.json, whose SHA-256 matches the library):
+
+```
+%s
+```
+""" % later)
 print("avg trace launch %.1f us; derived:" % avg_us, {k: round(v, 3) for k, v in d.items()})
