@@ -219,12 +219,12 @@ static void apply_tuning_knobs(rt_ctx *c) {
     DevSceneParams &p = c->dev.p;
     const DevSceneParams &d = c->host.params;
     p.tri_min_lanes = d.tri_min_lanes; p.donate = d.donate; p.refill_min_idle = d.refill_min_idle; p.donate_min_idle = d.donate_min_idle;
-    p.prune_err = d.prune_err; p.prune_rel = d.prune_rel; p.cone_off = 0; p.min_chunk = d.min_chunk;
-    p.interleave_shift = d.interleave_shift; p.interleave_max_share = d.interleave_max_share;
+    p.prune_err = d.prune_err; p.prune_rel = d.prune_rel; p.cone_off = 0;
+    p.interleave_shift = d.interleave_shift; p.interleave_max_share = d.interleave_max_share; p.tail_window_waves = d.tail_window_waves;
+    if (const char *tw = getenv("RT_TAIL_WINDOW")) p.tail_window_waves = clampi(atoi(tw), 0, 64);
     if (const char *ig = getenv("RT_INTERLEAVE_SHIFT")) p.interleave_shift = clampi(atoi(ig), 0, 6);
     if (const char *im = getenv("RT_INTERLEAVE_MAX_SHARE")) p.interleave_max_share = clampi(atoi(im), 0, 1 << 30);
     rt_set_trace_block_cap(0);
-    if (const char *mc = getenv("RT_MIN_CHUNK")) p.min_chunk = clampi(atoi(mc), 1, 64);
     if (const char *sb = getenv("RT_SMALL_RAYS_PER_BLOCK")) rt_set_small_rays_per_block(atoi(sb));
     if (const char *nc = getenv("RT_NO_CONE")) p.cone_off = atoi(nc) ? 1 : 0;
     if (const char *cap = getenv("RT_TRACE_BLOCK_CAP")) rt_set_trace_block_cap(std::max(0, atoi(cap)));
@@ -755,12 +755,22 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
             struct Rec { int lane, slot, n0; std::vector<int> est; };
             std::vector<Rec> recs;
             for (int j = 0; j < n_streams; ++j) HIP_TRY(c, c->lanes[j].d_counts.ensure(n_cnt * std::max<size_t>(1, slots)));
+            // Batches that run side by side (one per stream) are enqueued level by level, so that no stream's launches wait for the
+            // host to finish another stream's whole chain; more batches than streams: one batch after the other.
+            const bool level_major = n_batches > 1 && n_batches <= (int64_t)n_streams;
+            std::vector<int> lasts;
             for (int64_t b = 0; b < n_batches; ++b) {
                 StreamLane &ln = c->lanes[(size_t)(b % n_streams)];
                 const int slot = (int)(b / n_streams);
                 int *counts = ln.d_counts.p + (size_t)slot * n_cnt;
                 ln.p0 = next_p0;
                 ln.np = (int)std::min<int64_t>(batch_pixels, n_owned - next_p0);
+#ifdef RT_TUNING_KNOBS
+                if (level_major && n_batches == 2 && getenv("RT_SPLIT_PCT")) {       // experiment: unequal halves (the second gets this share)
+                    const int64_t second = std::max<int64_t>(256, n_owned * std::min(90, std::max(5, atoi(getenv("RT_SPLIT_PCT")))) / 100 / 256 * 256);
+                    ln.np = (int)(b == 0 ? n_owned - second : n_owned - next_p0);
+                }
+#endif
                 next_p0 += ln.np;
                 const int n0 = ln.np * spp;
                 primary_rays += (uint64_t)n0;
@@ -787,14 +797,30 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
                 ln.levels[(size_t)last + 1].count = 0;
                 rt_launch_raygen(ln.stream, dc, c->d_pixels.p, (int)ln.p0, n0, ln.levels[0].view());
                 rt_launch_fill_int(ln.stream, counts, (int)n_cnt, 0);
-                for (int k = 0; k <= last; ++k) {
-                    ln.k = k;
-                    int rc = enqueue_level(ln, counts, true, k < last ? rec.est[(size_t)k + 1] : 0);
+                lasts.push_back(last);
+                if (!level_major) {
+                    for (int k = 0; k <= last; ++k) {
+                        ln.k = k;
+                        int rc = enqueue_level(ln, counts, true, k < last ? rec.est[(size_t)k + 1] : 0);
+                        if (rc != RT_OK) return rc;
+                    }
+                    int rc = finish_batch(ln, counts, last, true);
                     if (rc != RT_OK) return rc;
                 }
-                int rc = finish_batch(ln, counts, last, true);
-                if (rc != RT_OK) return rc;
                 recs.push_back(std::move(rec));
+            }
+            if (level_major) {
+                for (int k = 0; k <= max_depth; ++k)
+                    for (size_t b = 0; b < recs.size(); ++b) {
+                        StreamLane &ln = c->lanes[(size_t)recs[b].lane];
+                        int *counts = ln.d_counts.p + (size_t)recs[b].slot * n_cnt;
+                        if (k <= lasts[b]) {
+                            ln.k = k;
+                            int rc = enqueue_level(ln, counts, true, k < lasts[b] ? recs[b].est[(size_t)k + 1] : 0);
+                            if (rc != RT_OK) return rc;
+                        }
+                        if (k == lasts[b]) { int rc = finish_batch(ln, counts, lasts[b], true); if (rc != RT_OK) return rc; }
+                    }
             }
             HIP_TRY(c, drain_lanes());
             // one read-back per frame: every batch's counters, after the streams have drained
@@ -873,7 +899,10 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
     };
 
     const bool can_predict = c->level_ratio.size() == (size_t)max_depth + 2 && !getenv("RT_HOST_COUNTS");
+    const bool want_tl = getenv("RT_TIMELINE") != nullptr;
+    if (want_tl) rt_tl_begin();
     int frc = run_frame(can_predict);
+    if (want_tl) rt_tl_end();
     if (frc == 1) {
         // a level outgrew the queue its prediction had sized (new camera, other sample count ...): once more, host-counted
         for (int j = 0; j < n_streams; ++j) HIP_TRY(c, hipStreamSynchronize(c->lanes[j].stream));
@@ -913,7 +942,7 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
         if (getenv("RT_TRACE_DEBUG")) {
             for (int q = 0; q < 2; ++q) {
                 fprintf(stderr, "[rt] trace lanes %s:", q ? "shadow" : "closest");
-                for (int k = 0; k < 10; ++k) fprintf(stderr, " %llu", hc.dbg[q][k]);
+                for (int k = 0; k < 14; ++k) fprintf(stderr, " %llu", hc.dbg[q][k]);
                 fprintf(stderr, "\n[rt] steps histogram (log2 buckets):");
                 for (int k = 0; k < 16; ++k) fprintf(stderr, " %llu", hc.hist[q * 16 + k]);
                 fprintf(stderr, "\n[rt] ns per node step by bucket:");

@@ -210,6 +210,10 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
         bool moving = o.motion_blur[0] != 0 || o.motion_blur[1] != 0 || o.motion_blur[2] != 0;   // Shape.h:111
         q.flags = (o.flags & RT_OBJ_SMOOTH ? DEV_OBJ_SMOOTH : 0) | (o.flags & RT_OBJ_HAS_XFORM ? DEV_OBJ_HAS_XFORM : 0) |
                   (o.flags & RT_OBJ_COMPOSITE ? DEV_OBJ_COMPOSITE : 0) | (moving ? DEV_OBJ_MOTION : 0) | (mat_is_identity(Mt) ? DEV_OBJ_IDENTITY : 0);
+        {   // bit for bit the unit matrix, not moving: the object-space ray of every such object is the same
+            static const float unit[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+            if ((o.flags & RT_OBJ_HAS_XFORM) && !moving && std::memcmp(q.M, unit, sizeof(unit)) == 0) q.flags |= DEV_OBJ_UNIT;
+        }
         q.material = o.material; q.tex_color = o.tex_color; q.tex_normal = o.tex_normal;
         q.cone_k = (o.flags & RT_OBJ_HAS_XFORM) ? cone_k_of_matrix(q.M) : 1.0f;
     }
@@ -567,11 +571,12 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
     hs.params.n_lights = d->n_lights; hs.params.n_materials = d->n_materials; hs.params.n_textures = d->n_textures;
     hs.params.bvh_depth = maxDepth;
     hs.params.flt_max = 3.402823466e+38f;
-    hs.params.min_chunk = 64;
     hs.params.interleave_shift = 0;             // measured on config 2 (1 spp): runs of 1 / 4 / 8 / 16 neighbours: 9.20 / 9.23 / 9.35 / 9.41 ms, none: 9.73
     hs.params.interleave_max_share = 1024;      // launches above ~16 rays per lane balance through the queue; interleaving them costs 4 % (coherence)
     hs.params.tri_min_lanes = RT_TRI_MIN_LANES;
     hs.params.donate = 1;
+    hs.params.tl_slot = -1;
+    hs.params.tail_window_waves = 1;
     hs.params.refill_min_idle = RT_REFILL_MIN_IDLE;
     hs.params.donate_min_idle = RT_DONATE_MIN_IDLE;
     hs.params.has_normal_tex = 0; hs.params.has_rng = 0;
@@ -580,6 +585,8 @@ int rt_build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err,
     for (const rt_material &m : hs.materials) if (m.roughness > 0) hs.params.has_rng = 1;
     hs.params.has_motion = 0;
     hs.params.n_objects = (int32_t)hs.objects.size();
+    hs.params.unit_object = -1;
+    for (size_t i = 0; i < hs.objects.size() && i < 24; ++i) if (hs.objects[i].flags & DEV_OBJ_UNIT) { hs.params.unit_object = (int32_t)i; break; }
     for (const DevObject &o : hs.objects) if (o.flags & DEV_OBJ_MOTION) hs.params.has_motion = 1;
     float scale = 1.0f;
     if (!bn.empty() || device_done)

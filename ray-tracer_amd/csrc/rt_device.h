@@ -57,7 +57,8 @@ struct alignas(64) DevPrim {
 };
 static_assert(sizeof(DevPrim) == 64, "DevPrim must be 64 bytes");
 
-enum { DEV_OBJ_SMOOTH = 1, DEV_OBJ_HAS_XFORM = 2, DEV_OBJ_COMPOSITE = 4, DEV_OBJ_MOTION = 8, DEV_OBJ_IDENTITY = 16 };
+enum { DEV_OBJ_SMOOTH = 1, DEV_OBJ_HAS_XFORM = 2, DEV_OBJ_COMPOSITE = 4, DEV_OBJ_MOTION = 8, DEV_OBJ_IDENTITY = 16,
+       DEV_OBJ_UNIT = 32 };   // static object whose matrix is bit for bit the unit matrix (1.0f / +0.0f): all such objects share one object-space ray
 
 // 160 bytes; matrices in glm order m[col*4+row].
 struct alignas(16) DevObject {
@@ -105,10 +106,12 @@ struct DevSceneParams {
     float isect_eps_p1;       // 1 + isect_eps in float (Triangle.cpp:219): a kernel argument so that it stays in a scalar register
     float flt_max;            // FLT_MAX as a kernel argument: a literal would sit in a vector register of the traversal loop, which
                               // the register allocator spills and reloads (with a wait for every outstanding load) once per node step
-    int32_t min_chunk;        // smallest number of rays a wave of the traversal reserves at a time (small launches)
     int32_t cone_off;         // tuning builds only (RT_NO_CONE): prune far children without the normal-cone test (NOT exact)
     int32_t interleave_shift; // log2 of the run of consecutive queue entries a wave takes from one place (6: the whole chunk, no interleaving)
     int32_t interleave_max_share;  // interleave only launches with at most this many rays per wave of the grid
+    int32_t unit_object;      // a DEV_OBJ_UNIT object among the first objects (the traversal's LDS table), or -1
+    int32_t tail_window_waves; // the traversal reserves exactly one ray per idle lane once the queue is within this many grids' worth of rays of its end (0: never)
+    int32_t tl_slot;          // tuning builds only: slot of the launch-timeline record this launch fills (-1: none)
 };
 #define RT_NO_ROOT 0x7fffffff
 

@@ -16,6 +16,9 @@
 // Wave64 throughout; the traversal stack lives in LDS (one 4-byte column per lane, bank == lane, conflict-free).
 #include <float.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "rt_cone.h"
 #include "rt_math.h"
 #include "rt_wavefront.h"
@@ -355,7 +358,19 @@ __device__ __noinline__ bool chain_visit(const DevChain *chain, int node, bool l
 #define PAY_DZ 13
 #define PAY_DLEN 14              // |d| (normal-cone test of a child that is about to be pruned by distance)
 
-struct TraceDbg { unsigned nodes, boxes, tris, sph, v[10]; };
+struct TraceDbg { unsigned nodes, boxes, tris, sph, v[14]; };
+
+// Timeline builds only (make TUNE=1 TL=1; the extra live values cost the traversal loop registers, so never otherwise): per trace
+// launch and wave, when the wave started, when it found the queue empty, when it left the traversal loop (100 MHz ticks).
+// RT_TIMELINE=1 prints the percentiles per launch of a frame.
+#ifdef RT_TIMELINE_BUILD
+#define TL_SLOTS 32
+#define TL_WAVES 4096
+__device__ unsigned long long g_tl[TL_SLOTS * TL_WAVES * 4];
+#define TL_SET(k) do { if (sc.p.tl_slot >= 0 && (threadIdx.x & 63) == 0) g_tl[((size_t)sc.p.tl_slot * TL_WAVES + (blockIdx.x * (TRACE_BLOCK / 64) + (threadIdx.x >> 6))) * 4 + (k)] = (unsigned long long)wall_clock64(); } while (0)
+#else
+#define TL_SET(k) do { } while (0)
+#endif
 
 // Traversal stack: LDS_STACK entries per lane in LDS ([entry][thread], conflict-free), deeper entries in a global column.
 // The overflow accesses are volatile so that the compiler keeps two separate paths (ds_* and global_*) instead of one
@@ -397,10 +412,13 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
     unsigned long long ray_t0 = 0;
     bool exhausted = false;          // wave-uniform: the global queue has no more chunks
     int chunk_next = 0, chunk_end = 0;
-    // Rays a wave reserves per atomic.  A launch with fewer rays than the grid has lanes hands every wave an equal share instead
-    // of 64 to the first waves and none to the rest: the launch then lasts as long as its longest ray, and the idle lanes of
-    // every wave can start taking over parts of its long rays (donation) at once.
-    int chunk = TRACE_CHUNK;
+    // Rays a wave reserves per atomic: TRACE_CHUNK while the queue is long.  A wave that reserves 64 rays with 16 idle lanes keeps
+    // 48 of them waiting for its own lanes; once the queue is within `tail_window` positions of its end those rays are what the
+    // launch's last waves are still busy with while the lanes of every other wave idle, so from there on a wave reserves
+    // exactly as many rays as it has idle lanes (one atomic per refill round instead of one per 64 rays).
+    const int tail_window = sc.p.tail_window_waves * (int)gridDim.x * (TRACE_BLOCK / 64) * TRACE_CHUNK;
+    int last_base = 0;               // queue position of the wave's latest reservation (wave-uniform)
+    const int chunk = TRACE_CHUNK;
     // Queue positions -> ray indices.  Neighbouring rays are about equally long, so a launch with only a few rays per lane ends
     // when the wave that drew the longest 64 neighbours ends.  Such launches are interleaved: position 64 c + q (chunk c, slot q)
     // is ray (q >> s) * (C << s) + (c << s) + (q & (2^s - 1)) with C chunks in all, so that a wave draws 64 >> s runs of 2^s
@@ -409,8 +427,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
     int il_shift = 6, il_chunks = 0, npos = n;
     {
         const int waves = gridDim.x * (TRACE_BLOCK / 64);
-        const int share = (n + waves - 1) / waves;
-        if (share < TRACE_CHUNK) chunk = share < sc.p.min_chunk ? sc.p.min_chunk : share;
+        const int share = (int)(((long long)n + waves - 1) / waves);
         if (sc.p.interleave_shift < 6 && share <= sc.p.interleave_max_share) { il_shift = sc.p.interleave_shift; il_chunks = (n + 63) >> 6; npos = il_chunks << 6; }
     }
     // work donation (see the retire block): a lane may hand the bottom entry of its stack to an idle lane of the wave
@@ -421,6 +438,11 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
 
     for (;;) {
         if (COUNT) { ++dbg.v[0]; if (has_ray && cur != CUR_DONE) ++dbg.v[1]; }
+#ifdef RT_VALU_PROBE
+        // issue-slot probe: RT_VALU_PROBE x 8 vector no-ops per iteration (how much of the loop's time is VALU issue?)
+#pragma unroll
+        for (int q = 0; q < RT_VALU_PROBE; ++q) asm volatile("v_nop\n v_nop\n v_nop\n v_nop\n v_nop\n v_nop\n v_nop\n v_nop");
+#endif
         // ---------------- retire finished rays, refill idle lanes (batched) ----------------
         // When the queue is exhausted the wave would run on with a few long rays and mostly idle lanes (config 2: 2-6 rays per
         // lane and launch, so this phase is a large part of every launch).  Then lanes that still have stack entries DONATE
@@ -480,12 +502,14 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                 if (nidle >= sc.p.refill_min_idle && (!exhausted || chunk_next < chunk_end)) {
                     // 3a. new rays from the wave's chunk of the queue
                     if (chunk_next >= chunk_end) {
+                        const int want = (npos - last_base <= tail_window) ? nidle : chunk;
                         int base = 0;
-                        if (lane == 0) base = atomicAdd(fetch_counter, chunk);
+                        if (lane == 0) base = atomicAdd(fetch_counter, want);
                         base = __shfl(base, 0);
+                        last_base = base;
                         chunk_next = base;
-                        chunk_end = base + chunk < npos ? base + chunk : npos;
-                        if (base + chunk >= npos) exhausted = true;
+                        chunk_end = base + want < npos ? base + want : npos;
+                        if (base + want >= npos) { exhausted = true; TL_SET(1); }
                     }
                     const int avail = chunk_end > chunk_next ? chunk_end - chunk_next : 0;
                     const int rank = __popcll(idle & lt_mask);
@@ -523,6 +547,9 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                                 marg = mk3(err * fabsf(r.x) * 1.000001f, err * fabsf(r.y) * 1.000001f, err * fabsf(r.z) * 1.000001f);
                                 cur = sc.p.root;
                                 has_ray = true;
+                                // The object-space ray of the scene's unit-matrix objects (Triangle.cpp:141-161 transforms and renormalises
+                                // also then, Q8) is prepared here, once per ray and with many lanes, instead of in the primitive path.
+                                if (sc.p.unit_object >= 0) enter_object<MOTION>(sc, objc, sc.p.unit_object, o, d, time, xf);
                             } else {
                                 Cand none;
                                 none.t = FLT_MAX; none.prim = -1; none.ip = mk3(0, 0, 0); none.beta = none.gamma = 0;
@@ -563,6 +590,9 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                         const float rx = __shfl(r.x, src), ry = __shfl(r.y, src), rz = __shfl(r.z, src);
                         const float mx = __shfl(marg.x, src), my = __shfl(marg.y, src), mz = __shfl(marg.z, src);
                         const float tm = MOTION ? __shfl(time, src) : 0.0f, am = __shfl(amb, src), bd = __shfl(bound, src);
+                        const int xi = __shfl(xf.id, src), xg = __shfl(xf.flags, src);
+                        const float xox = __shfl(xf.o.x, src), xoy = __shfl(xf.o.y, src), xoz = __shfl(xf.o.z, src);
+                        const float xdx = __shfl(xf.d.x, src), xdy = __shfl(xf.d.y, src), xdz = __shfl(xf.d.z, src);
                         const int en = entry;
                         if (take) {
                             o = mk3(ox, oy, oz); dirx = dx; r = mk3(rx, ry, rz); marg = mk3(mx, my, mz);
@@ -573,7 +603,8 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                             pay[PAY_DLEN * TRACE_BLOCK] = pay[PAY_DLEN * TRACE_BLOCK + (src - lane)];
                             payi[PAY_PENDING * TRACE_BLOCK] = 0;
                             best_t = bd; bound = bd; best_prim = -1;      // nothing at or beyond the giver's bound can win
-                            sp = sbase = 0; xf.id = -2; prim_i = prim_end = 0;
+                            sp = sbase = 0; prim_i = prim_end = 0;
+                            xf.id = xi; xf.flags = xg; xf.o = mk3(xox, xoy, xoz); xf.d = mk3(xdx, xdy, xdz);      // the giver's object-space ray is this ray's
                             plane = src; cur = en; has_ray = true;
                             if (COUNT) { ray_steps = 0; ++dbg.v[3]; }
                         }
@@ -582,7 +613,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                 }
             }
         }
-        if (!__any(has_ray)) { if (exhausted && chunk_next >= chunk_end) break; else continue; }
+        if (!__any(has_ray) && exhausted && chunk_next >= chunk_end) break;      // (a wave between two chunks just runs an empty iteration)
 
         // pruning bound: own best, and for a donated part whatever its parent has found meanwhile (all lanes take part)
         bound = fminf(bound, best_t);
@@ -636,7 +667,10 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
             if (do_tri) {
                 // ProcessIntersectionForLeafNode (BVHTree.cpp:177-190): fresh result per leaf, array order, accept t>0 && t < local-0.001
                 const int obj = p_obj, kind = p_kind;
-                if (obj != xf.id) enter_object<MOTION>(sc, objc, obj, o, mk3(dirx, pay[PAY_DY * TRACE_BLOCK], pay[PAY_DZ * TRACE_BLOCK]), time, xf);
+                // every unit-matrix object has the same object-space ray (and the same matrices for the way back)
+                bool same = obj == xf.id;
+                if (!same && (xf.flags & DEV_OBJ_UNIT) && obj < OBJ_CACHE) same = (__float_as_int(objc[obj * OBJ_CACHE_DWORDS + 32]) & DEV_OBJ_UNIT) != 0;
+                if (!same) enter_object<MOTION>(sc, objc, obj, o, mk3(dirx, pay[PAY_DY * TRACE_BLOCK], pay[PAY_DZ * TRACE_BLOCK]), time, xf);
                 Cand c;
                 bool ok;
                 if (kind == DEV_PRIM_TRIANGLE) {
@@ -697,8 +731,11 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
             if (any_far) {
                 const float dy = pay[PAY_DY * TRACE_BLOCK], dz = pay[PAY_DZ * TRACE_BLOCK], dl = pay[PAY_DLEN * TRACE_BLOCK];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (far[i] && (sc.p.cone_off || cone_allows_prune(ccone[i], dirx, dy, dz, dl))) cls[i] = 0;
+                for (int i = 0; i < 4; ++i) {
+                    const bool prune = far[i] && (sc.p.cone_off || cone_allows_prune(ccone[i], dirx, dy, dz, dl));
+                    if (COUNT && far[i]) { ++dbg.v[10]; if (prune) ++dbg.v[11]; else if ((ccone[i] >> 24) == RT_CONE_NEVER) ++dbg.v[12]; else ++dbg.v[13]; }
+                    if (prune) cls[i] = 0;
+                }
             }
             if (need_chain && amb < 1.0f) {
                 need_chain = false;
@@ -901,14 +938,16 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(4))
         __syncthreads();
     }
     n = io.resolve(n, n_dev);                     // queue lengths that were produced on the device
+    TL_SET(0);
     TraceDbg dbg;
     dbg.nodes = dbg.boxes = dbg.tris = dbg.sph = 0;
-    for (int k = 0; k < 10; ++k) dbg.v[k] = 0;
+    for (int k = 0; k < 14; ++k) dbg.v[k] = 0;
     trace_persistent<COUNT, MOTION, IO>(sc, io, n, fetch_counter, (lds_int *)s_stack + threadIdx.x, (lds_float *)s_pay + threadIdx.x, (const lds_float *)s_obj, ovf, ovf_stride, dbg,
                                         (COUNT && counters && counters->want_hist) ? &counters->hist[0] : nullptr);
+    TL_SET(3);
     flush_counters<COUNT>(counters, dbg.nodes, dbg.boxes, dbg.tris, dbg.sph);
     if (COUNT && counters) {
-        for (int k = 0; k < 10; ++k) {
+        for (int k = 0; k < 14; ++k) {
             unsigned v = dbg.v[k];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
             if ((threadIdx.x & 63) == 0) atomicAdd(&counters->dbg[IO::DBG_SET][k], (unsigned long long)v);
@@ -970,9 +1009,50 @@ static void trace_dispatch(hipStream_t s, const DevScene &sc, IO io, int n, cons
 }
 // `fetch_counter` must point to a zeroed int that no other launch in flight uses.  n_closest rays of lv (may be 0) and the
 // shadow queue sb (its length is read on the device; `shadow_bound` >= that length sizes the launch; 0 = no shadow part).
-void rt_launch_trace(hipStream_t s, const DevScene &sc, LevelBuf lv, int n_closest, const int *closest_dev, ShadowBuf sb, int shadow_bound, int *fetch_counter, int *ovf,
+#ifdef RT_TIMELINE_BUILD
+static int g_tl_next = -1;            // -1: timeline off
+void rt_tl_begin() {
+    void *p = nullptr;
+    hipGetSymbolAddress(&p, HIP_SYMBOL(g_tl));
+    hipMemset(p, 0, sizeof(unsigned long long) * TL_SLOTS * TL_WAVES * 4);
+    g_tl_next = 0;
+}
+void rt_tl_end() {
+    static std::vector<unsigned long long> h((size_t)TL_SLOTS * TL_WAVES * 4);
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_tl), h.size() * sizeof(unsigned long long));
+    const int n = g_tl_next;
+    g_tl_next = -1;
+    unsigned long long prev_end = 0;
+    for (int i = 0; i < n && i < TL_SLOTS; ++i) {
+        std::vector<double> st, ex, en;
+        unsigned long long t0 = ~0ull, t3 = 0;
+        for (int w = 0; w < TL_WAVES; ++w) { const unsigned long long *r = &h[((size_t)i * TL_WAVES + w) * 4]; if (r[0]) { t0 = std::min(t0, r[0]); t3 = std::max(t3, r[3]); } }
+        if (t0 == ~0ull) continue;
+        for (int w = 0; w < TL_WAVES; ++w) {
+            const unsigned long long *r = &h[((size_t)i * TL_WAVES + w) * 4];
+            if (!r[0]) continue;
+            st.push_back((r[0] - t0) * 0.01); if (r[1]) ex.push_back((r[1] - t0) * 0.01); en.push_back((r[3] - t0) * 0.01);
+        }
+        auto pct = [](std::vector<double> &v, double q) { if (v.empty()) return -1.0; std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
+        fprintf(stderr, "[tl] launch %d (%zu waves): gap %.1f | start p50 %.1f max %.1f | queue empty first %.1f p50 %.1f | wave exit p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f us\n",
+                i, st.size(), prev_end ? ((double)t0 - (double)prev_end) * 0.01 : 0.0, pct(st, 0.5), pct(st, 1.0), pct(ex, 0.0), pct(ex, 0.5),
+                pct(en, 0.1), pct(en, 0.5), pct(en, 0.9), pct(en, 0.99), pct(en, 1.0));
+        prev_end = t3;
+    }
+}
+#else
+void rt_tl_begin() {}
+void rt_tl_end() {}
+#endif
+void rt_launch_trace(hipStream_t s, const DevScene &sc_in, LevelBuf lv, int n_closest, const int *closest_dev, ShadowBuf sb, int shadow_bound, int *fetch_counter, int *ovf,
                      DevCounters *counters) {
     if (n_closest <= 0 && shadow_bound <= 0) return;
+    DevScene sc = sc_in;
+    sc.p.tl_slot = -1;
+#ifdef RT_TIMELINE_BUILD
+    if (g_tl_next >= 0 && g_tl_next < TL_SLOTS) sc.p.tl_slot = g_tl_next++;
+#endif
     RenderIO io; io.lv = lv; io.n_closest = n_closest > 0 ? n_closest : 0; io.closest_dev = n_closest > 0 ? closest_dev : nullptr; io.sb = sb;
     io.shadow_cap = shadow_bound > 0 ? shadow_bound : 0;
     const dim3 g(trace_blocks(io.n_closest + io.shadow_cap)), b(TRACE_BLOCK);

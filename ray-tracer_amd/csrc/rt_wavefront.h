@@ -67,8 +67,10 @@ struct DevCounters {        // accumulated with atomics when counting is enabled
     unsigned long long node_visits, box_tests, tri_tests, sphere_tests;
     // lane-occupancy diagnostics of the persistent traversal (lane-summed; printed when RT_TRACE_DEBUG is set):
     // 0 outer iterations x64, 1 lanes holding a ray, 2 refill rounds x64, 3 lanes refilled, 4 node steps x64, 5 lanes stepping,
-    // 6 leaf primitive iterations x64, 7 lanes testing a primitive, 8 exact-slab fallback rounds x64, 9 lanes needing it
-    unsigned long long dbg[2][10];   // [closest | shadow]
+    // 6 leaf primitive iterations x64, 7 lanes testing a primitive, 8 exact-slab fallback rounds x64, 9 lanes needing it,
+    // 10 children whose box begins beyond the best hit, 11 of those skipped (the normal cone allows it), 12 entered because the
+    // cone word is "never", 13 entered because the ray lies inside the cone's band
+    unsigned long long dbg[2][14];   // [closest | shadow]
     unsigned long long want_hist;     // set by the host when RT_TRACE_DEBUG asks for the per-ray histogram (three atomics per ray)
     unsigned long long hist[96];      // rays by floor(log2(node steps))+1, [closest 16 | shadow 16]; then ticks (100 MHz) and steps per bucket
 };
@@ -79,6 +81,8 @@ void rt_launch_raygen(hipStream_t s, const DevCamera &cam, const int *pixel_list
 // Queue lengths: every launcher takes (n, n_dev).  n_dev == nullptr: the queue holds n entries.  Otherwise the real length is
 // the device counter *n_dev (a level whose size the host never reads back) and n is its upper bound = the capacity the
 // queue was allocated with; the kernels use min(*n_dev, n) and the grid is sized for n.
+void rt_tl_begin();              // tuning builds: per-launch wave timeline (RT_TIMELINE=1); no-ops otherwise
+void rt_tl_end();
 void rt_launch_trace(hipStream_t s, const DevScene &sc, LevelBuf lv, int n_closest, const int *closest_dev, ShadowBuf sb, int shadow_bound, int *fetch_counter,
                      int *overflow_stack, DevCounters *counters);
 void rt_launch_trace_batch(hipStream_t s, const DevScene &sc, const rt_ray *rays, rt_hit *hits, int n, int *fetch_counter, int *overflow_stack, DevCounters *counters,
