@@ -338,6 +338,14 @@ int rt_scene_upload(rt_ctx *c, const rt_scene_desc *scene) {
     UPLOAD(c, c->d_texels, h.texels);
     DevScene &d = c->dev;
     d.p = h.params;
+    {   // the traversal reads node records through a buffer descriptor with 32-bit offsets
+        const uint64_t nb = (uint64_t)h.info.n_wide_nodes * sizeof(DevNode4);
+        if (nb > 0xffffff00ull) { c->error = "too many BVH nodes for the traversal's 32-bit node offsets (limit 2^25 - 2 wide nodes)"; return RT_ERR_TOO_LARGE; }
+        d.p.node_bytes = (uint32_t)nb;
+        const uint64_t pb = (uint64_t)h.info.n_leaf_prims * sizeof(DevPrim);
+        if (pb > 0xffffff00ull) { c->error = "too many primitive records for the traversal's 32-bit offsets (limit 2^26 - 4)"; return RT_ERR_TOO_LARGE; }
+        d.p.prim_bytes = (uint32_t)pb;
+    }
     d.nodes = c->d_nodes.p; d.chain = c->d_chain.p; d.node_chain = c->d_node_chain.p; d.leaves = c->d_leaves.p; d.prims = c->d_prims.p; d.objects = c->d_objects.p; d.verts = c->d_verts.p;
     d.tri_vert = c->d_tri_vert.p; d.materials = c->d_materials.p; d.lights = c->d_lights.p; d.textures = c->d_textures.p; d.texels = c->d_texels.p;
     // traversal stack overflow area: entries beyond the LDS part, one column per persistent thread
@@ -444,6 +452,7 @@ int rt_scene_import(rt_ctx *c, const void *header, const void *const arenas[RT_S
 #undef RT_IMPORT
     DevScene &d = c->dev;
     d.p = hd.params;
+    if (hd.arena_bytes[0] > 0xffffff00ull || (uint64_t)d.p.node_bytes > hd.arena_bytes[0] || hd.arena_bytes[4] > 0xffffff00ull || (uint64_t)d.p.prim_bytes > hd.arena_bytes[4]) { c->error = "scene header does not match its node arena"; return RT_ERR_INVALID; }
     d.nodes = c->d_nodes.p; d.chain = c->d_chain.p; d.node_chain = c->d_node_chain.p; d.leaves = c->d_leaves.p; d.prims = c->d_prims.p; d.objects = c->d_objects.p; d.verts = c->d_verts.p;
     d.tri_vert = c->d_tri_vert.p; d.materials = c->d_materials.p; d.lights = c->d_lights.p; d.textures = c->d_textures.p; d.texels = c->d_texels.p;
     c->overflow_depth = std::max(0, hd.params.stack_bound + 2 - rt_trace_lds_stack_depth());

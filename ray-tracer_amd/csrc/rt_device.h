@@ -109,6 +109,8 @@ struct DevSceneParams {
     int32_t cone_off;         // tuning builds only (RT_NO_CONE): prune far children without the normal-cone test (NOT exact)
     int32_t interleave_shift; // log2 of the run of consecutive queue entries a wave takes from one place (6: the whole chunk, no interleaving)
     int32_t interleave_max_share;  // interleave only launches with at most this many rays per wave of the grid
+    uint32_t node_bytes;      // size of the DevNode4 array in bytes (range of the traversal's buffer descriptor), at most 0xffffff00
+    uint32_t prim_bytes;      // the same for the DevPrim array
     int32_t unit_object;      // a DEV_OBJ_UNIT object among the first objects (the traversal's LDS table), or -1
     int32_t tail_window_waves; // the traversal reserves exactly one ray per idle lane once the queue is within this many grids' worth of rays of its end (0: never)
     int32_t tl_slot;          // tuning builds only: slot of the launch-timeline record this launch fills (-1: none)

@@ -391,8 +391,8 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                                                  int *ovf, int ovf_stride, TraceDbg &dbg, unsigned long long *hist) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const float4 *nodes4 = reinterpret_cast<const float4 *>(sc.nodes);
-    const float4 *prims4 = reinterpret_cast<const float4 *>(sc.prims);
+    const __amdgpu_buffer_rsrc_t node_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.nodes, 0, sc.p.node_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t prim_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sc.prims, 0, sc.p.prim_bytes, 0x00020000);
     const float eps = sc.p.isect_eps;
     const bool no_scene = sc.p.root == RT_NO_ROOT;
 
@@ -643,23 +643,26 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
         const int n_leaf = __popcll(__ballot(in_leaf)), n_node = __popcll(__ballot(at_node));
         const bool run_tri = n_leaf > 0 && (n_leaf >= sc.p.tri_min_lanes || n_node == 0);      // wave-uniform
         const bool do_tri = in_leaf && run_tri;
-        float4 p0 = make_float4(0, 0, 0, 0), p1 = p0;
-        float p2x = 0;
-        int p_obj = 0, p_kind = 0;
-        // only the lanes that will use a record request it: an idle lane's load would cost the vector cache as many tag
-        // look-ups as a working lane's
-        if (do_tri) {
-            const float4 *prec = prims4 + 4 * (size_t)prim_i;
-            p0 = prec[0]; p1 = prec[1];
-            const float4 p2 = prec[2];                       // e2.z, object, kind, shape (DevPrim, rt_device.h)
-            p2x = p2.x; p_obj = __float_as_int(p2.y); p_kind = __float_as_int(p2.z);
-        }
-        float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0, q6 = q0, q7 = q0;
-        const float4 *rec = nodes4 + 8 * (size_t)(at_node ? cur : 0);
-        // the cone words (q7) only matter to a lane that can prune by distance, i.e. one that has a bound when the loads go out; a bound
+        // Primitive record (the same way as the node record below: a lane that tests no primitive asks beyond the range)
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        const unsigned poff = do_tri ? (unsigned)prim_i * 64u : 0xffffff00u;
+        const v4u pr0 = __builtin_amdgcn_raw_buffer_load_b128(prim_rsrc, (int)poff, 0, 0), pr1 = __builtin_amdgcn_raw_buffer_load_b128(prim_rsrc, (int)poff + 16, 0, 0),
+                  pr2 = __builtin_amdgcn_raw_buffer_load_b128(prim_rsrc, (int)poff + 32, 0, 0);      // e2.z, object, kind, shape (DevPrim, rt_device.h)
+        const float4 p0 = make_float4(__uint_as_float(pr0.x), __uint_as_float(pr0.y), __uint_as_float(pr0.z), __uint_as_float(pr0.w));
+        const float4 p1 = make_float4(__uint_as_float(pr1.x), __uint_as_float(pr1.y), __uint_as_float(pr1.z), __uint_as_float(pr1.w));
+        const float p2x = __uint_as_float(pr2.x);
+        int p_obj = (int)pr2.y, p_kind = (int)pr2.z;
+        // Node record: eight 16-byte pieces through a buffer descriptor.  A lane without a node asks for an offset beyond the
+        // descriptor's range: the range check answers 0 without touching memory, so no branch, no merging of "loaded" and "not
+        // loaded" registers (the flat form cost 32 register clears per iteration) and 32-bit offsets instead of 64-bit addresses.
+        // the cone words (piece 7) only matter to a lane that can prune by distance, i.e. one that has a bound when the loads go out; a bound
         // found by this iteration's primitive test prunes from the next node step on (what loads the vector memory path is lanes x loads)
         const bool can_prune = bound < sc.p.flt_max;
-        if (at_node) { q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3]; q4 = rec[4]; q5 = rec[5]; q6 = rec[6]; if (can_prune) q7 = rec[7]; }
+        const unsigned voff = at_node ? (unsigned)cur * 128u : 0xffffff00u, voff7 = (at_node && can_prune) ? voff : 0xffffff00u;
+#define NODE_PIECE(k, off) const v4u r##k = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, (int)(off) + 16 * k, 0, 0); \
+                           const float4 q##k = make_float4(__uint_as_float(r##k.x), __uint_as_float(r##k.y), __uint_as_float(r##k.z), __uint_as_float(r##k.w))
+        NODE_PIECE(0, voff); NODE_PIECE(1, voff); NODE_PIECE(2, voff); NODE_PIECE(3, voff); NODE_PIECE(4, voff); NODE_PIECE(5, voff); NODE_PIECE(6, voff); NODE_PIECE(7, voff7);
+#undef NODE_PIECE
         // keeps the compiler from testing the primitive's kind (and waiting for it) before the node loads above are issued
         asm volatile("" : "+v"(p_kind), "+v"(p_obj) : : "memory");
         if (COUNT) { ++dbg.v[4]; if (at_node) ++dbg.v[5]; if (do_tri) ++dbg.v[7]; if (run_tri) ++dbg.v[6]; }
