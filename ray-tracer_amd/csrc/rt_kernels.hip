@@ -266,8 +266,8 @@ __device__ __forceinline__ int slab_fast(float bminx, float bminy, float bminz, 
     const float nz = fminf(az, bz), fz = fmaxf(az, bz);
     const float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
     const float tf = fminf(fminf(fx, fy), fminf(fz, FLT_MAX));
-    float lb = fmaxf(fmaxf(nx - marg.x, ny - marg.y), nz - marg.z) - marg.x;
-    lb = lb - fabsf(lb) * 2e-6f;
+    // (the caller compares lb with the bound scaled by 1 + 3e-6: the relative slack of the bound, paid once per node step instead of per child)
+    const float lb = fmaxf(fmaxf(nx - marg.x, ny - marg.y), nz - marg.z) - marg.x;
     tn_out = tn; lb_out = lb;
     const float diff = tf - tn;
     const float thr = amb * (fabsf(tf) + fabsf(tn));
@@ -712,6 +712,9 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
             bool need_chain = false;
             int cls[4];
             bool far[4], any_far = false;
+            // a child is "far" when its conservative lower bound lies beyond the best hit by more than 3e-6 relative (without a hit
+            // the bound is FLT_MAX and the product +inf: never far)
+            const float bound_far = bound * 1.000003f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float tn, lb;
@@ -720,7 +723,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                 // The child's box begins beyond the best hit (an undecided box never does).  It is skipped only if no triangle
                 // below it is so nearly in a plane with the ray that the reference's Cramer solve could put a "hit" anywhere
                 // on the ray (rt_cone.h) — decided after this loop, for the lanes that have such a child.
-                far[i] = c == 1 && can_prune && lb > bound;
+                far[i] = c == 1 && can_prune && lb > bound_far;      // can_prune: the cone words were only requested by lanes that had a bound then
                 any_far = any_far || far[i];
                 // An undecided LEAF is decided exactly by the chain walk.  An undecided INTERNAL child of an ordinary ray (grazing
                 // its box) is simply entered: boxes nest, so that is conservative and cheap.  A ray with a zero direction component
@@ -728,7 +731,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene &sc, const IO io
                 // for it the internal child gets the reference's exact test of its own box.
                 if (c == 2) { if (cref[i] < 0 || !(amb < 1.0f)) need_chain = true; else c = 1; }
                 cls[i] = c;
-                key[i] = fminf(fmaxf(tn, 0.0f), sc.p.flt_max);    // NaN -> 0, +inf -> FLT_MAX (+inf marks a child that is not taken)
+                key[i] = fminf(tn, sc.p.flt_max);    // tn >= 0, never NaN (maxima with 0); +inf -> FLT_MAX (+inf marks a child that is not taken)
             }
             if (COUNT) { ++dbg.nodes; dbg.boxes += 4; ++ray_steps; }
             if (any_far) {
