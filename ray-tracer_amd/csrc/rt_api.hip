@@ -452,7 +452,10 @@ int rt_scene_import(rt_ctx *c, const void *header, const void *const arenas[RT_S
 #undef RT_IMPORT
     DevScene &d = c->dev;
     d.p = hd.params;
-    if (hd.arena_bytes[0] > 0xffffff00ull || (uint64_t)d.p.node_bytes > hd.arena_bytes[0] || hd.arena_bytes[4] > 0xffffff00ull || (uint64_t)d.p.prim_bytes > hd.arena_bytes[4]) { c->error = "scene header does not match its node arena"; return RT_ERR_INVALID; }
+    // the ranges of the traversal's buffer descriptors are those of the arenas that actually arrived
+    if (hd.arena_bytes[0] > 0xffffff00ull || hd.arena_bytes[4] > 0xffffff00ull) { c->error = "imported scene too large for the traversal's 32-bit record offsets"; return RT_ERR_TOO_LARGE; }
+    d.p.node_bytes = (uint32_t)(hd.arena_bytes[0] / sizeof(DevNode4) * sizeof(DevNode4));
+    d.p.prim_bytes = (uint32_t)(hd.arena_bytes[4] / sizeof(DevPrim) * sizeof(DevPrim));
     d.nodes = c->d_nodes.p; d.chain = c->d_chain.p; d.node_chain = c->d_node_chain.p; d.leaves = c->d_leaves.p; d.prims = c->d_prims.p; d.objects = c->d_objects.p; d.verts = c->d_verts.p;
     d.tri_vert = c->d_tri_vert.p; d.materials = c->d_materials.p; d.lights = c->d_lights.p; d.textures = c->d_textures.p; d.texels = c->d_texels.p;
     c->overflow_depth = std::max(0, hd.params.stack_bound + 2 - rt_trace_lds_stack_depth());
