@@ -27,7 +27,9 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 5u
+#define RT_ABI_VERSION 6u
+#define RT_MAX_BATCH_RAYS 0x7ff00000u   /* most rays one rt_intersect_batch / rt_intersect_batch_noalloc call takes (the queue positions of the
+                                           persistent waves stay below 2^31 with every wave one chunk past the end) */
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -209,6 +211,10 @@ typedef struct rt_render_opts {
     int32_t max_batch_samples;/* samples traced per wavefront batch; <=0 selects the default (8M)      */
     int32_t timing;           /* 1: bracket kernels with HIP events and fill rt_stats ms fields        */
     int32_t num_streams;      /* sub-batches in flight on separate HIP streams; <=0 selects the default (1), max 8 */
+    int32_t level_counts;     /* 0: after a scene's first frame the lengths of the ray queues stay on the device (no host round
+                                 trip between ray generation and resolve; rt_stats.frame_passes = 2 when a prediction failed);
+                                 1: the host reads every level's length (one round trip per level, exact queue sizes)       */
+    int32_t _reserved;
 } rt_render_opts;
 
 enum { RT_RAY_PRIMARY = 0, RT_RAY_SHADOW = 1, RT_RAY_REFLECT = 2, RT_RAY_REFRACT = 3, RT_RAY_KINDS = 4 };

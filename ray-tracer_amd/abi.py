@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-RT_ABI_VERSION = 5
+RT_ABI_VERSION = 6
 
 RT_OK, RT_ERR_INVALID, RT_ERR_ABI, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_NO_SCENE, RT_ERR_TOO_LARGE = 0, -1, -2, -3, -4, -5, -6
 
@@ -85,7 +85,8 @@ class RenderOpts(C.Structure):
     _fields_ = [
         ("abi_version", C.c_uint32), ("seed", C.c_uint32), ("tile_size", C.c_int32), ("tile_rank", C.c_int32),
         ("tile_world", C.c_int32), ("output_on_device", C.c_int32), ("compact_output", C.c_int32),
-        ("max_batch_samples", C.c_int32), ("timing", C.c_int32), ("num_streams", C.c_int32)]
+        ("max_batch_samples", C.c_int32), ("timing", C.c_int32), ("num_streams", C.c_int32), ("level_counts", C.c_int32),
+        ("_reserved", C.c_int32)]
 
 
 class Stats(C.Structure):

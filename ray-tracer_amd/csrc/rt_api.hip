@@ -36,6 +36,11 @@ namespace {
 std::string g_create_error;
 enum { RT_MAX_DEVICES = 64 };
 int *g_noalloc_scratch[RT_MAX_DEVICES];      // per device: address of `scratch` on that device (set in rt_ctx_create)
+// rt_intersect_batch_noalloc shares that scratch between all its calls on a device: a call that is enqueued while an earlier one
+// on ANOTHER stream has not finished would race with it for the fetch counter.  The event marks the end of the latest call.
+hipEvent_t g_noalloc_done[RT_MAX_DEVICES];
+hipStream_t g_noalloc_stream[RT_MAX_DEVICES];
+bool g_noalloc_pending[RT_MAX_DEVICES];
 
 #define HIP_TRY(ctx, expr)                                                                                     \
     do {                                                                                                       \
@@ -138,6 +143,7 @@ enum { RT_DEFAULT_STREAMS = 1, RT_MAX_STREAMS = 8 };
 
 struct rt_ctx {
     int device = 0;
+    int num_cus = 256;          // compute units of `device`: the persistent grid and the stack-overflow areas of this context are sized by it
     hipStream_t stream = nullptr;
     std::string error;
     bool has_scene = false;
@@ -174,6 +180,7 @@ struct rt_ctx {
     int overflow_depth = 0;
     std::vector<double> level_ratio;        // rays per primary sample of every level in the last frame (empty: no frame of this scene yet)
     uint64_t mispredicted_frames = 0;       // frames that had to be rendered a second time because a level outgrew its predicted queue
+    int wide_margin_frames = 0;             // frames still to be rendered with the wide queue margin (set after a misprediction)
     std::vector<hipEvent_t> ev_pool;        // timing events, kept between frames (creating one costs several microseconds)
     size_t ev_used = 0;
     hipError_t timing_event(hipEvent_t *out) {
@@ -253,22 +260,27 @@ int rt_ctx_create(int hip_device_id, rt_ctx **out) {
         return RT_ERR_NO_DEVICE;
     }
     if (hip_device_id < 0 || hip_device_id >= n) { g_create_error = "hip_device_id out of range"; return RT_ERR_INVALID; }
+    int num_cus = 256;
     e = hipSetDevice(hip_device_id);
     if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return RT_ERR_HIP; }
     {
         hipDeviceProp_t prop;
         e = hipGetDeviceProperties(&prop, hip_device_id);
         if (e != hipSuccess) { g_create_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e); return RT_ERR_HIP; }
-        rt_set_num_cus(prop.multiProcessorCount);
+        num_cus = prop.multiProcessorCount;
+        rt_set_num_cus(num_cus);
     }
     if (hip_device_id < RT_MAX_DEVICES && !g_noalloc_scratch[hip_device_id]) {     // once per device, with that device current
         int *ptr = nullptr;
         e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
         if (e != hipSuccess || !ptr) { g_create_error = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e); return RT_ERR_HIP; }
+        e = hipEventCreateWithFlags(&g_noalloc_done[hip_device_id], hipEventDisableTiming);      // created here, once: the entry point itself allocates nothing
+        if (e != hipSuccess) { g_create_error = std::string("hipEventCreate: ") + hipGetErrorString(e); return RT_ERR_HIP; }
         g_noalloc_scratch[hip_device_id] = ptr;
     }
     rt_ctx *c = new rt_ctx();
     c->device = hip_device_id;
+    c->num_cus = num_cus;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete c; return RT_ERR_HIP; }
     std::memset(&c->dev, 0, sizeof(c->dev));
@@ -296,6 +308,7 @@ const char *rt_last_error(const rt_ctx *c) { return c ? c->error.c_str() : g_cre
 int rt_scene_upload(rt_ctx *c, const rt_scene_desc *scene) {
     if (!c) return RT_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
+    rt_set_num_cus(c->num_cus);
     c->has_scene = false;
     c->level_ratio.clear();
     if (scene && scene->abi_version == RT_ABI_VERSION && scene->n_spheres > 0 && scene->sph_object && scene->objects)
@@ -378,9 +391,24 @@ struct SceneHeader {
     uint32_t magic, abi_version;
     uint32_t record_bytes[RT_SCENE_ARENAS];      // element size of every arena: a library with other record layouts must refuse the bytes
     uint64_t arena_bytes[RT_SCENE_ARENAS];
+    uint64_t arena_mark[RT_SCENE_ARENAS];     // FNV-1a of each arena's first and last 256 bytes: ties the header to the arrays it was exported with
     rt_bvh_info info;
     DevSceneParams params;
 };
+// fingerprint of an arena that lives at `src` (device or host memory): its first and last min(256, bytes) bytes
+int arena_mark(rt_ctx *c, const void *src, uint64_t bytes, uint64_t *out) {
+    unsigned char buf[512];
+    const size_t k = (size_t)std::min<uint64_t>(256, bytes);
+    *out = 0xcbf29ce484222325ull ^ bytes;
+    if (!k) return RT_OK;
+    HIP_TRY(c, hipMemcpyAsync(buf, src, k, hipMemcpyDefault, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(buf + k, (const unsigned char *)src + (bytes - k), k, hipMemcpyDefault, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint64_t h = *out;
+    for (size_t i = 0; i < 2 * k; ++i) { h ^= buf[i]; h *= 0x100000001b3ull; }
+    *out = h;
+    return RT_OK;
+}
 const uint32_t kSceneMagic = 0x4e435352u;        // "RSCN"
 const uint32_t kRecordBytes[RT_SCENE_ARENAS] = {sizeof(DevNode4), sizeof(DevChain), sizeof(int32_t), sizeof(DevLeaf), sizeof(DevPrim), sizeof(DevObject),
                                                 sizeof(DevVertex), sizeof(int32_t), sizeof(rt_material), sizeof(rt_light), sizeof(rt_texture), 1};
@@ -402,6 +430,8 @@ int rt_scene_export(rt_ctx *c, void *header, uint64_t arena_bytes[RT_SCENE_ARENA
     for (int i = 0; i < RT_SCENE_ARENAS; ++i) { hd.record_bytes[i] = kRecordBytes[i]; hd.arena_bytes[i] = c->arena_bytes[i]; arena_bytes[i] = c->arena_bytes[i]; }
     hd.info = c->host.info;
     hd.params = c->host.params;
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (int i = 0; i < RT_SCENE_ARENAS; ++i) { const int rc = arena_mark(c, arena_ptr(c, i), c->arena_bytes[i], &hd.arena_mark[i]); if (rc != RT_OK) return rc; }
     std::memcpy(header, &hd, sizeof(hd));
     return RT_OK;
 }
@@ -412,6 +442,7 @@ int rt_scene_export_arena(rt_ctx *c, int index, void *dst) {
     if (c->arena_bytes[index] == 0) return RT_OK;
     if (!dst) { c->error = "rt_scene_export_arena: dst is NULL"; return RT_ERR_INVALID; }
     HIP_TRY(c, hipSetDevice(c->device));
+    rt_set_num_cus(c->num_cus);
     HIP_TRY(c, hipMemcpyAsync(dst, arena_ptr(c, index), c->arena_bytes[index], hipMemcpyDefault, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RT_OK;
@@ -420,6 +451,7 @@ int rt_scene_export_arena(rt_ctx *c, int index, void *dst) {
 int rt_scene_import(rt_ctx *c, const void *header, const void *const arenas[RT_SCENE_ARENAS]) {
     if (!c || !header || !arenas) return RT_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
+    rt_set_num_cus(c->num_cus);
     SceneHeader hd;
     std::memcpy(&hd, header, sizeof(hd));
     if (hd.magic != kSceneMagic) { c->error = "rt_scene_import: not a scene header"; return RT_ERR_INVALID; }
@@ -435,6 +467,26 @@ int rt_scene_import(rt_ctx *c, const void *header, const void *const arenas[RT_S
         p.n_textures < 0 || (uint64_t)p.n_textures * sizeof(rt_texture) != hd.arena_bytes[10] || p.n_objects < 0 || (uint64_t)p.n_objects * sizeof(DevObject) != hd.arena_bytes[5] ||
         (p.root != RT_NO_ROOT && p.root >= 0 && (uint64_t)p.root >= n_wide) || hd.arena_bytes[2] != 4 * n_wide * sizeof(int32_t) || (p.root != RT_NO_ROOT && n_prims == 0) ||
         p.stack_bound < 0 || p.stack_bound > (1 << 20) || p.bg_texture >= p.n_textures) { c->error = "rt_scene_import: header inconsistent with its arenas"; return RT_ERR_INVALID; }
+    {   // a traversal stack sized too small, a root leaf outside the primitive records or arrays of another export would be
+        // out-of-bounds accesses in the kernels, not errors: refuse them here
+        const uint64_t n_leaves = hd.arena_bytes[3] / sizeof(DevLeaf);
+        bool ok = hd.info.n_wide_nodes >= 0 && (uint64_t)hd.info.n_wide_nodes == n_wide && hd.info.max_depth >= 0;
+        // a 4-wide tree of depth w has at most (4^w - 1) / 3 nodes, and its traversal stack needs 3 w + 2 entries
+        int w = 0;
+        for (uint64_t cap = 0; cap < n_wide; cap = 4 * cap + 1) ++w;
+        ok = ok && p.stack_bound >= 3 * w + 2;
+        if (p.root != RT_NO_ROOT && p.root < 0) {
+            const uint32_t u = (uint32_t)~p.root, start = u & ((1u << DEV_LEAF_START_BITS) - 1), count = u >> DEV_LEAF_START_BITS;
+            ok = ok && (count ? (uint64_t)start + count <= n_prims : (uint64_t)start < n_leaves);
+        }
+        if (!ok) { c->error = "rt_scene_import: header inconsistent with its arenas"; return RT_ERR_INVALID; }
+        for (int i = 0; i < RT_SCENE_ARENAS; ++i) {
+            uint64_t mark = 0;
+            const int rc = arena_mark(c, arenas[i], hd.arena_bytes[i], &mark);
+            if (rc != RT_OK) return rc;
+            if (mark != hd.arena_mark[i]) { c->error = "rt_scene_import: an arena is not the one this header was exported with"; return RT_ERR_INVALID; }
+        }
+    }
     c->has_scene = false;
     c->level_ratio.clear();
     c->host = HostScene();
@@ -559,6 +611,7 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
     if (opts->tile_world > 1 && (opts->tile_rank < 0 || opts->tile_rank >= opts->tile_world)) { c->error = "tile_rank outside tile_world"; return RT_ERR_INVALID; }
     const auto t_begin = std::chrono::steady_clock::now();
     HIP_TRY(c, hipSetDevice(c->device));
+    rt_set_num_cus(c->num_cus);
     hipStream_t s = c->stream;
     const DevCamera dc = make_camera(cam, opts->seed);
     const int spp = dc.spp;
@@ -771,6 +824,28 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
             // host to finish another stream's whole chain; more batches than streams: one batch after the other.
             const bool level_major = n_batches > 1 && n_batches <= (int64_t)n_streams;
             std::vector<int> lasts;
+            const double margin = c->wide_margin_frames > 0 ? 1.5 : 1.0625;
+            if (c->wide_margin_frames > 0) --c->wide_margin_frames;
+            {   // all queues of all streams are sized for the largest batch BEFORE the first launch: nothing is allocated (and so
+                // nothing synchronises the device) between ray generation and resolve
+                const int64_t n0_max = std::min<int64_t>(batch_pixels, n_owned) * spp;
+                double prev = (double)n0_max;
+                for (int k = 0; k <= max_depth; ++k) {
+                    double est = prev;
+                    if (k > 0) {
+                        const double r = c->level_ratio[(size_t)k];
+                        if (!(r > 0.0) || prev == 0) break;
+                        est = std::min(std::min(r * (double)n0_max * margin + 4096.0, 2.0 * prev), (double)0x3fffffff);
+                    }
+                    const size_t nsh = (size_t)est * (size_t)std::max(1, nl);
+                    if (nsh > 0x3fffffff) { c->error = "shadow queue too large; lower max_batch_samples"; return RT_ERR_TOO_LARGE; }
+                    for (int j = 0; j < n_streams; ++j) {
+                        HIP_TRY(c, c->lanes[j].levels[(size_t)k].ensure((size_t)est));
+                        HIP_TRY(c, c->lanes[j].sh[k & 1].ensure(nsh));
+                    }
+                    prev = (double)(int)est;
+                }
+            }
             for (int64_t b = 0; b < n_batches; ++b) {
                 StreamLane &ln = c->lanes[(size_t)(b % n_streams)];
                 const int slot = (int)(b / n_streams);
@@ -793,7 +868,7 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
                 for (int k = 1; k <= max_depth; ++k) {
                     const double r = c->level_ratio[(size_t)k];
                     if (!(r > 0.0) || rec.est[(size_t)k - 1] == 0) break;
-                    const double want = r * (double)n0 * 1.0625 + 4096.0;
+                    const double want = r * (double)n0 * margin + 4096.0;
                     rec.est[(size_t)k] = (int)std::min<double>(std::min<double>(want, 2.0 * (double)rec.est[(size_t)k - 1]), (double)0x3fffffff);
                 }
                 int last = 0;
@@ -910,7 +985,9 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
         return RT_OK;
     };
 
-    const bool can_predict = c->level_ratio.size() == (size_t)max_depth + 2 && !getenv("RT_HOST_COUNTS");
+    // rt_render_opts.level_counts = 1: the host reads every level's length (one round trip per level); 0: lengths stay on the device
+    // whenever the scene has been rendered before.  After a frame whose prediction failed the next frames get a wider margin.
+    const bool can_predict = c->level_ratio.size() == (size_t)max_depth + 2 && opts->level_counts != 1;
     const bool want_tl = getenv("RT_TIMELINE") != nullptr;
     if (want_tl) rt_tl_begin();
     int frc = run_frame(can_predict);
@@ -919,6 +996,7 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
         // a level outgrew the queue its prediction had sized (new camera, other sample count ...): once more, host-counted
         for (int j = 0; j < n_streams; ++j) HIP_TRY(c, hipStreamSynchronize(c->lanes[j].stream));
         ++c->mispredicted_frames;
+        c->wide_margin_frames = 8;           // a sequence whose ray counts keep growing should not render every frame twice
         frc = run_frame(false);
     }
     if (frc != RT_OK) {
@@ -996,9 +1074,11 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
 
 int rt_intersect_batch(rt_ctx *c, const rt_ray *rays, size_t n, rt_hit *hits, int on_device, rt_stats *stats) {
     if (!c) return RT_ERR_INVALID;
-    if ((n && (!rays || !hits)) || n > 0x7fffffff) { c->error = "bad ray batch"; return RT_ERR_INVALID; }
+    if (n && (!rays || !hits)) { c->error = "bad ray batch"; return RT_ERR_INVALID; }
+    if (n > RT_MAX_BATCH_RAYS) { c->error = "more than RT_MAX_BATCH_RAYS rays in one call"; return RT_ERR_TOO_LARGE; }
     if (!c->has_scene) { c->error = "no scene uploaded"; return RT_ERR_NO_SCENE; }
     HIP_TRY(c, hipSetDevice(c->device));
+    rt_set_num_cus(c->num_cus);
     apply_tuning_knobs(c);
     hipStream_t s = c->stream;
     const rt_ray *dr = rays; rt_hit *dh = hits;
@@ -1045,9 +1125,10 @@ size_t rt_noalloc_scratch_bytes(void) { return sizeof(int) * ((size_t)NOALLOC_HE
 int rt_intersect_batch_noalloc(rt_ctx *c, const rt_ray *d_rays, size_t n, rt_hit *d_hits, void *hip_stream) {
     if (!c) return RT_ERR_INVALID;
     if ((n && (!d_rays || !d_hits))) { c->error = "rt_intersect_batch_noalloc: NULL ray or hit buffer"; return RT_ERR_INVALID; }
-    if (n > 0x7fffffff) { c->error = "rt_intersect_batch_noalloc: more than 2^31-1 rays in one call"; return RT_ERR_TOO_LARGE; }
+    if (n > RT_MAX_BATCH_RAYS) { c->error = "rt_intersect_batch_noalloc: more than RT_MAX_BATCH_RAYS rays in one call"; return RT_ERR_TOO_LARGE; }
     if (!c->has_scene) { c->error = "no scene uploaded"; return RT_ERR_NO_SCENE; }
     HIP_TRY(c, hipSetDevice(c->device));
+    rt_set_num_cus(c->num_cus);
     int *ptr = c->device < RT_MAX_DEVICES ? g_noalloc_scratch[c->device] : nullptr;
     if (!ptr) { c->error = "rt_intersect_batch_noalloc: no scratch address for this device"; return RT_ERR_INVALID; }
     // the overflow area holds `depth` stack entries for each persistent thread: fewer blocks for a deeper tree
@@ -1056,12 +1137,26 @@ int rt_intersect_batch_noalloc(rt_ctx *c, const rt_ray *d_rays, size_t n, rt_hit
     if (fit < 1) { c->error = "rt_intersect_batch_noalloc: the scene's BVH is too deep for the fixed scratch (stack overflow depth " + std::to_string(depth) + ")"; return RT_ERR_TOO_LARGE; }
     const int blocks = (int)std::min<int64_t>(fit, rt_trace_resident_blocks());
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    // Overlapping calls on one GPU share the scratch.  Calls on one stream are ordered; a call on another stream while the latest
+    // one is still running is refused.  (A stream under graph capture executes nothing now: its replays are the caller's to order.)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (!capturing && g_noalloc_pending[c->device] && g_noalloc_stream[c->device] != s && hipEventQuery(g_noalloc_done[c->device]) == hipErrorNotReady) {
+        c->error = "rt_intersect_batch_noalloc: an earlier call on another stream of this GPU is still running (the calls share one scratch buffer)";
+        return RT_ERR_INVALID;
+    }
+    (void)hipGetLastError();
     if (n) {
         rt_launch_fill_int(s, ptr, 1, 0);        // the fetch counter starts at zero; the overflow columns need no clearing (written before read)
         rt_launch_trace_batch(s, c->dev, d_rays, d_hits, (int)n, ptr, ptr + NOALLOC_HEADER_INTS, nullptr, blocks, blocks * tb);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { c->error = std::string("kernel launch failed: ") + hipGetErrorString(e); return RT_ERR_HIP; }
+    if (!capturing && n) {
+        HIP_TRY(c, hipEventRecord(g_noalloc_done[c->device], s));
+        g_noalloc_stream[c->device] = s; g_noalloc_pending[c->device] = true;
+    }
     if (!hip_stream) HIP_TRY(c, hipStreamSynchronize(s));
     return RT_OK;
 }
@@ -1150,6 +1245,7 @@ int rt_image_encode(rt_ctx *c, const float *hdr_rgb, int nx, int ny, int hdr_on_
     const int64_t npx = (int64_t)nx * ny;
     if (npx > 0x7fffffff / 4) { c->error = "rt_image_encode: frame larger than 2^29 pixels"; return RT_ERR_TOO_LARGE; }
     HIP_TRY(c, hipSetDevice(c->device));
+    rt_set_num_cus(c->num_cus);
     hipStream_t s = c->stream;
     const float *d_hdr = hdr_rgb;
     if (!hdr_on_device) {
@@ -1221,6 +1317,7 @@ int rt_tonemap(rt_ctx *c, const float *hdr_rgb, int nx, int ny, const rt_tonemap
     const int64_t npx = (int64_t)nx * ny;
     if (npx > 0x7fffffff / 4) { c->error = "rt_tonemap: frame larger than 2^29 pixels"; return RT_ERR_TOO_LARGE; }
     HIP_TRY(c, hipSetDevice(c->device));
+    rt_set_num_cus(c->num_cus);
     hipStream_t s = c->stream;
     const float *d_hdr = hdr_rgb;
     if (!o->in_on_device) {
@@ -1263,6 +1360,7 @@ static int ply_decode_device(rt_ctx *c, const void *vertex_bytes, const void *fa
         L->face_post_bytes < 0) { c->error = "rt_ply_decode: bad argument"; return RT_ERR_INVALID; }
     if (nv > 0x7fffffffLL || nf > 0x3fffffffLL) { c->error = "rt_ply_decode: more than 2^31 vertices or 2^30 faces"; return RT_ERR_TOO_LARGE; }
     HIP_TRY(c, hipSetDevice(c->device));
+    rt_set_num_cus(c->num_cus);
     hipStream_t s = c->stream;
     HIP_TRY(c, c->d_ply_pos.ensure((size_t)nv * 3 + 1));
     HIP_TRY(c, c->d_ply_tri.ensure((size_t)nf * 6 + 1));

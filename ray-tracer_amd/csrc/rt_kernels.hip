@@ -27,9 +27,10 @@
 #define LDS_STACK 20
 #define TRACE_RESIDENT_PER_CU 4      // blocks of the traversal kernel a CU holds (128 VGPRs, 39 KB LDS each of the 160 KB)
 
-// compute units of the device the library runs on (hipDeviceProp_t::multiProcessorCount, set by rt_ctx_create; 256 on MI355X):
-// sizes the persistent grid of the traversal and its stack-overflow area
-static int g_num_cus = 256;
+// compute units of the device the calling thread's context runs on (hipDeviceProp_t::multiProcessorCount; 256 on MI355X): sizes the
+// persistent grid of the traversal and its stack-overflow area.  Every entry point of rt_api.hip sets it from its context, so that
+// contexts on devices of different size (or on different host threads) never share the value.
+static thread_local int g_num_cus = 256;
 void rt_set_num_cus(int n) { if (n > 0) g_num_cus = n; }
 int rt_trace_grid_threads() { return g_num_cus * TRACE_RESIDENT_PER_CU * TRACE_BLOCK; }
 int rt_trace_lds_stack_depth() { return LDS_STACK; }
