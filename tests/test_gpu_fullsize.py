@@ -83,3 +83,83 @@ def test_config5_geometry_largest_the_oracle_finishes(rt, orc, gpu_ctx):
     at 20 instances x 200 000 triangles (4 M triangles) and 1280x720 at 4 spp."""
     soup = synth.instanced_scene(20, 200_000, 1280, 720, 4, perlin_table=rt.renderer.perlin_tables(1)[0])
     run_full(rt, orc, gpu_ctx, soup, "config 5 geometry (20 x 200k)")
+
+
+class _Heartbeat:
+    """Appends a line to gpurun_out/ every 20 s while a long CPU step runs (the oracle builds a 54 M-primitive tree on one core)."""
+    def __init__(self, label):
+        import os, threading
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        self.path = os.path.join(root, "gpurun_out", "test_progress.log")
+        self.label, self.stop = label, threading.Event()
+        self.t = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import os
+        t0 = time.time()
+        while not self.stop.wait(20.0):
+            try:
+                os.makedirs(os.path.dirname(self.path), exist_ok=True)
+                with open(self.path, "a") as f:
+                    f.write("%s: %.0f s\n" % (self.label, time.time() - t0))
+            except OSError:
+                pass
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop.set()
+
+
+def test_config5_defining_size_rows_vs_oracle_and_properties(rt, orc, gpu_ctx):
+    """BASELINE config 5 at the size that defines it: 50 MeshInstances of the 1 M-triangle mesh (52 M triangles, 54 M reference
+    primitives), 3840x2160, described compactly and expanded in HBM.  One sample per pixel (the 256-spp frame is 15.6 G rays).
+    Oracle half: every 64th row of the frame (34 rows, 130 560 pixels) through the CPU oracle, which builds the full reference tree
+    of the written-out scene: identical primary (shape, t), colours within the tolerance of tests/parity_util.py.
+    Property half, at full size: the frame is deterministic, the union of 8 tile ranks is the whole frame bit for bit with equal
+    ray counts, and the written-out description gives the same frame as the compact one.
+    If the host cannot hold 50 instances the largest count that fits is used and printed."""
+    nx, ny, step = 3840, 2160, 64
+    perlin = rt.renderer.perlin_tables(1)[0]
+    for n_inst in (50, 25, 10):
+        try:
+            soup = synth.instanced_scene(n_inst, 1_000_000, nx, ny, 1, perlin_table=perlin, compact=True)
+            full = soup.expanded()
+            break
+        except MemoryError:
+            continue
+    else:
+        pytest.fail("not even 10 instances fit the host")
+    print("config 5: %d instances, %d triangles written out" % (n_inst, len(full.tri_vert)), flush=True)
+    gpu_ctx.upload(soup)
+    g_hdr, g_id, g_t, g_st = gpu_ctx.render(0, seed=3, timing=1)
+    g2_hdr, g2_id, _, g2_st = gpu_ctx.render(0, seed=3, timing=1)
+    assert np.array_equal(g_hdr.view(np.uint32), g2_hdr.view(np.uint32)) and np.array_equal(g_id, g2_id) and list(g_st.rays) == list(g2_st.rays)
+    assert g2_st.level_syncs == 0 and g2_st.frame_passes == 1
+    # union of 8 tile ranks == whole frame
+    union = np.zeros((nx * ny, 3), np.float32)
+    rays8 = np.zeros(4, np.int64)
+    for r in range(8):
+        part, _, _, st = gpu_ctx.render(0, seed=3, want_ids=False, tile_size=32, tile_rank=r, tile_world=8, compact_output=True)
+        union[rt.renderer.tile_pixel_order(nx, ny, 32, r, 8)] = part
+        rays8 += np.asarray(list(st.rays), np.int64)
+    assert np.array_equal(union.view(np.uint32), g_hdr.reshape(-1, 3).view(np.uint32)), "tile union differs from the full frame"
+    assert list(rays8) == list(g_st.rays)
+    # oracle on every 64th row
+    with _Heartbeat("config 5: oracle tree of %d primitives" % len(full.prim_shape)):
+        t0 = time.time()
+        osc = orc.OracleScene(full)
+        build_s = time.time() - t0
+        c_hdr, c_id, c_t, c_st = osc.render(0, seed=3, nthreads=16, dynamic=True, row_step=step)
+        osc.close()
+    rows = np.arange(0, ny, step)
+    m = compare_frames(g_hdr[rows], c_hdr[rows], g_id[rows], c_id[rows], g_t[rows], c_t[rows])
+    assert (c_id[rows] >= 0).mean() > 0.2                                   # the rows do see the instances
+    print("config 5 at %dx%d, %d instances: %d rays in %.1f ms of kernels; oracle tree %.0f s, %d rows (%d rays): %s" % (
+        nx, ny, n_inst, sum(g_st.rays), g2_st.ms_kernels, build_s, len(rows), sum(c_st.rays), m), flush=True)
+    # written-out description == compact description (the scene leaves the host as 52 M explicit triangles this time)
+    gpu_ctx.upload(full)
+    w_hdr, w_id, _, w_st = gpu_ctx.render(0, seed=3)
+    assert np.array_equal(w_hdr.view(np.uint32), g_hdr.view(np.uint32)) and np.array_equal(w_id, g_id) and list(w_st.rays) == list(g_st.rays)
