@@ -129,3 +129,25 @@ def test_ascii_layout_counts_tokens(tmp_path):
         fmt, elements = scene._ply_header(f)
     L = scene.ply_layout(elements, ascii=True)
     assert (L.face_pre_bytes, L.face_post_bytes, L.vertex_stride) == (1, 1, 3)
+
+
+def test_reference_ply_files_pin_the_oracle_reader(scene_path):
+    """The four PLY files the reference ships (src/scenes/ply/) went through the oracle's reader in the build container
+    (tools/make_ply_golden.py); tests/golden/ref_ply_digests.json holds counts and SHA-256 digests of what it decoded.  The scene
+    fixtures scenes/tap_0200.npz and scenes/cube_point.npz were produced from the same files by the Python loader's own PLY reader
+    (another implementation, which numbers a mesh's vertices in the order the faces first use them): every PLY mesh is one object
+    of the fixture, and the corner positions of its triangles, in face order, must be bit for bit what the oracle's reader decoded
+    (SceneParser.cpp:983-1023: positions rounded to float, quads split into (0,1,2), (2,3,0))."""
+    import hashlib
+    import json
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_ply_digests.json")))
+    for scene, files in (("tap_0200", ["tap_tap", "tap_water_200"]), ("cube_point", ["plane", "cube"])):
+        d = np.load(scene_path(scene), allow_pickle=False)
+        pos, tri, obj = np.asarray(d["vert_pos"], np.float32), np.asarray(d["tri_vert"], np.int64), np.asarray(d["tri_object"])
+        digests = {}
+        for o in np.unique(obj):
+            rows = tri[obj == o]
+            digests[hashlib.sha256(np.ascontiguousarray(pos[rows]).tobytes()).hexdigest()] = len(rows)
+        for f in files:
+            g = gold[f]
+            assert digests.get(g["sha256_triangle_corners_f32"]) == g["n_triangles"], (scene, f)
