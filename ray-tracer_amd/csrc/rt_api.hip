@@ -194,7 +194,7 @@ struct rt_ctx {
     DevArray<unsigned long long> d_img_len, d_img_off;
     // PLY decoding
     DevArray<uint8_t> d_ply_in, d_ply_tmp;
-    DevArray<float> d_ply_pos;
+    DevArray<float> d_ply_pos, d_ply_fix;
     DevArray<int> d_ply_tri, d_ply_cnt, d_ply_flag;
     DevArray<long long> d_ply_off;
     DevArray<double> d_tm_partial;
@@ -213,7 +213,7 @@ static void release_all(rt_ctx *c) {
     c->d_rays.release(); c->d_hits.release();
     c->d_img_in.release(); c->d_tm_lum.release(); c->d_tm_out.release(); c->d_tm_params.release();
     c->d_img8.release(); c->d_img_text.release(); c->d_img_tmp.release(); c->d_img_len.release(); c->d_img_off.release(); c->d_tm_partial.release();
-    c->d_ply_in.release(); c->d_ply_tmp.release(); c->d_ply_pos.release(); c->d_ply_tri.release(); c->d_ply_cnt.release(); c->d_ply_flag.release(); c->d_ply_off.release();
+    c->d_ply_in.release(); c->d_ply_tmp.release(); c->d_ply_pos.release(); c->d_ply_fix.release(); c->d_ply_tri.release(); c->d_ply_cnt.release(); c->d_ply_flag.release(); c->d_ply_off.release();
 }
 
 // Experiment switches of the traversal (thresholds of the persistent loop, pruning margin).  Only compiled into tuning builds
@@ -1376,7 +1376,8 @@ static int ply_decode_device(rt_ctx *c, const void *vertex_bytes, const void *fa
         for (int k = 0; k < 3; ++k)
             if (L->pos_offset[k] < 0 || L->pos_offset[k] >= L->vertex_stride) { c->error = "rt_ply_decode: position token outside the vertex line"; return RT_ERR_INVALID; }
         const int64_t n_lines = nv + nf;
-        const int hard_cap = 1 << 16;
+        // every coordinate may be a number the device cannot convert exactly (20 significant digits, huge exponents, subnormals): room for all
+        const int hard_cap = (int)std::min<int64_t>(3 * nv, 0x1fffffff);
         size_t scan_bytes = 0, scan2 = 0;
         HIP_TRY(c, rt_ply_ascii_scan_bytes((int64_t)n_text, &scan_bytes));
         HIP_TRY(c, rt_ply_scan_bytes(nf, &scan2));
@@ -1405,9 +1406,10 @@ static int ply_decode_device(rt_ctx *c, const void *vertex_bytes, const void *fa
         if ((int64_t)n_lines_found + (last_open ? 1 : 0) < n_lines) { c->error = "rt_ply_decode: ascii body has fewer lines than vertices + faces"; return RT_ERR_INVALID; }
         if (bad & 1) { c->error = "rt_ply_decode: a vertex line has fewer values than the header declares"; return RT_ERR_INVALID; }
         if (bad & 2) { c->error = "rt_ply_decode: a face line is not a count followed by non-negative integer indices"; return RT_ERR_INVALID; }
-        if (n_hard > hard_cap) { c->error = "rt_ply_decode: too many numbers outside the device's exact decimal conversion"; return RT_ERR_TOO_LARGE; }
+        if (n_hard > hard_cap) { c->error = "rt_ply_decode: more unconverted numbers than the file has coordinates"; return RT_ERR_INVALID; }
         if (n_hard > 0) {
-            // tokens the device could not prove correct: the reference library's own conversion (operator>> of the property's type)
+            // tokens the device could not prove correct: the reference library's own conversion (operator>> of the property's type),
+            // all of them in one staging array, patched into the positions by one kernel
             std::vector<int> rec(3 * (size_t)n_hard);
             HIP_TRY(c, hipMemcpyAsync(rec.data(), d_hard + 1, rec.size() * sizeof(int), hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));
@@ -1418,8 +1420,10 @@ static int ply_decode_device(rt_ctx *c, const void *vertex_bytes, const void *fa
                 while (b < n_text && text[b] != ' ' && text[b] != '\n' && text[b] != '\r') ++b;
                 std::istringstream iss(std::string(text + a, b - a));
                 if (L->pos_type) { double v = 0; iss >> v; fixed[(size_t)h] = (float)v; } else { float v = 0; iss >> v; fixed[(size_t)h] = v; }
-                HIP_TRY(c, hipMemcpyAsync(c->d_ply_pos.p + 3 * (size_t)rec[3 * h] + rec[3 * h + 1], &fixed[(size_t)h], sizeof(float), hipMemcpyHostToDevice, s));
             }
+            HIP_TRY(c, c->d_ply_fix.ensure((size_t)n_hard));
+            HIP_TRY(c, hipMemcpyAsync(c->d_ply_fix.p, fixed.data(), fixed.size() * sizeof(float), hipMemcpyHostToDevice, s));
+            HIP_TRY(c, rt_ply_patch(s, d_hard, c->d_ply_fix.p, n_hard, c->d_ply_pos.p));
             HIP_TRY(c, hipStreamSynchronize(s));
         }
         n_tris = total;

@@ -297,3 +297,14 @@ hipError_t rt_ply_faces_mixed_write(hipStream_t s, const uint8_t *fb, const long
     hipLaunchKernelGGL(k_ply_faces_mixed, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, s, fb, offs, tri_off, (long long)nf, pre, csize, isize, out);
     return hipGetLastError();
 }
+
+// Tokens the device could not convert exactly were converted on the host: out[3 * vertex + coordinate] = value for every listed
+// triple (vertex, coordinate, byte offset) of `hard` (the list the vertex pass wrote, still in device memory).
+__global__ void k_ply_patch(const int *hard, const float *value, int n, float *out) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h < n) out[3 * (size_t)hard[1 + 3 * h] + hard[2 + 3 * h]] = value[h];
+}
+hipError_t rt_ply_patch(hipStream_t s, const int *hard, const float *value, int n, float *out) {
+    if (n > 0) hipLaunchKernelGGL(k_ply_patch, dim3((n + 255) / 256), dim3(256), 0, s, hard, value, n, out);
+    return hipGetLastError();
+}

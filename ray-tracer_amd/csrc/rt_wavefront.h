@@ -129,6 +129,7 @@ hipError_t rt_ply_ascii_faces_count(hipStream_t s, const uint8_t *text, const lo
                                     int *tri_off, void *scan_tmp, size_t scan_bytes, int *bad);
 hipError_t rt_ply_ascii_faces_write(hipStream_t s, const uint8_t *text, const long long *line_start, int64_t n_text, int64_t first_line, int64_t nf, int pre,
                                     const int *tri_off, int *out, int *bad);
+hipError_t rt_ply_patch(hipStream_t s, const int *hard, const float *value, int n, float *out);   // out[3 * vertex + coordinate] = value, per listed token
 hipError_t rt_ply_offset_copy(hipStream_t s, const int *src, int *dst, int64_t n, int offset);
 #define RT_TM_WORK_WORDS (4 + 2048)   // select state + histogram of rt_img_tonemap
 hipError_t rt_img_tonemap(hipStream_t s, const void *src, int from8, int64_t npx, float key, float burn_percent, float saturation,

@@ -43,7 +43,13 @@ class DeviceGeometry:
             vb, fb = memoryview(body)[:vbytes], memoryview(body)[vbytes:]
         v0, t0 = self.n_vertices, self.n_triangles
         torch.cuda.synchronize(self.device)                      # the decoder runs on the context's own stream
-        n = ctx.decode_ply_to(vb, fb, L, self.pos[v0:].data_ptr(), self.tri_vert[t0:].data_ptr(), index_offset=v0)
+        try:
+            n = ctx.decode_ply_to(vb, fb, L, self.pos[v0:].data_ptr(), self.tri_vert[t0:].data_ptr(), index_offset=v0)
+        except Exception as e:                                   # a body the device decoder refuses: the general host reader
+            if type(e).__name__ != "RtError":
+                raise
+            pos, tris = _scene._read_ply(path)
+            return self.add_host(pos, None, tris, obj)
         self.tri_object[t0:t0 + n] = int(obj)
         self.n_vertices, self.n_triangles = v0 + nv, t0 + n
         return v0, t0, n

@@ -586,18 +586,26 @@ def _read_ply(path, decoder=None):
     with open(path, "rb") as f:
         fmt, elements = _ply_header(f)
         tmap = _PLY_TYPES
-        if fmt == "binary_little_endian" and decoder is not None:
-            L = ply_layout(elements)
-            if L is not None:
-                body = f.read()
-                vbytes = int(L.n_vertices) * int(L.vertex_stride)
-                pos, tris = decoder(memoryview(body)[:vbytes], memoryview(body)[vbytes:], L)
-                return pos, tris.astype(np.int64)
-        if fmt == "ascii" and decoder is not None:
-            L = ply_layout(elements, ascii=True)
-            if L is not None:
-                pos, tris = decoder(memoryview(f.read()), b"", L)
-                return pos, tris.astype(np.int64)
+        body_at = f.tell()
+        # The device decoder takes the layouts real files have; a body it refuses (a face line it cannot parse, ...) goes to the
+        # general reader below, which reads whatever happly reads.
+        try:
+            if fmt == "binary_little_endian" and decoder is not None:
+                L = ply_layout(elements)
+                if L is not None:
+                    body = f.read()
+                    vbytes = int(L.n_vertices) * int(L.vertex_stride)
+                    pos, tris = decoder(memoryview(body)[:vbytes], memoryview(body)[vbytes:], L)
+                    return pos, tris.astype(np.int64)
+            if fmt == "ascii" and decoder is not None:
+                L = ply_layout(elements, ascii=True)
+                if L is not None:
+                    pos, tris = decoder(memoryview(f.read()), b"", L)
+                    return pos, tris.astype(np.int64)
+        except Exception as e:
+            if type(e).__name__ != "RtError":
+                raise
+        f.seek(body_at)
         verts, faces = None, []
         quads_tris = None
         if fmt == "ascii":

@@ -110,6 +110,39 @@ def test_ascii_random_decimals(rt, orc, gpu_ctx, tmp_path, pos_type):
     assert same.mean() > 0.999
 
 
+def test_ascii_every_coordinate_needs_the_host_conversion(rt, orc, gpu_ctx, tmp_path):
+    """A mesh written with 20 significant digits (setprecision(20)): the device can convert none of its 75 000 coordinates itself
+    (more than 19 digits), so every one of them goes through the hand-over list — which has room for all of a file's coordinates —,
+    is converted by the host the way the reference's reader does, and is patched in with one upload."""
+    rng = np.random.RandomState(5)
+    nv = 25_000
+    vals = (rng.rand(nv, 3) * 200 - 100) * (10.0 ** rng.randint(-3, 4, size=(nv, 1)))
+    rows = [["%.20g" % v for v in row] for row in vals]
+    assert all(len(t.replace("-", "").replace(".", "").lstrip("0")) >= 20 for t in rows[0])
+    faces = [[i, i + 1, i + 2] for i in range(0, nv - 2, 3)]
+    path = os.path.join(tmp_path, "p20.ply")
+    ply_util.write_ascii_ply(path, rows, faces)
+    g_pos, g_tris = scene._read_ply(path, gpu_ctx.decode_ply)
+    c_pos, c_tris = orc.ply_read(open(path, "rb").read())
+    assert np.array_equal(g_pos.view(np.uint32), c_pos.view(np.uint32)) and np.array_equal(g_tris, c_tris)
+
+
+def test_loader_falls_back_to_the_host_reader(rt, orc, gpu_ctx, tmp_path):
+    """A body the device decoder refuses must still load when the general reader (and happly) can read it: here the decoder is
+    made to refuse, and the loader's result equals the oracle reader's."""
+    path = os.path.join(tmp_path, "f.ply")
+    ply_util.make_ascii_case(path, "blender_tris")
+    calls = []
+
+    def refusing(vb, fb, layout):
+        calls.append(1)
+        raise rt.RtError(rt.abi.RT_ERR_TOO_LARGE, "refused for the test")
+
+    g_pos, g_tris = scene._read_ply(path, refusing)
+    c_pos, c_tris = orc.ply_read(open(path, "rb").read())
+    assert calls and np.array_equal(g_pos.astype(np.float32).view(np.uint32), c_pos.view(np.uint32)) and np.array_equal(g_tris, c_tris)
+
+
 def test_ascii_million_triangles(rt, orc, gpu_ctx, tmp_path):
     """The config-2 stand-in mesh as an ASCII PLY in Blender's spelling (the format of every PLY the reference ships): 500 k vertices,
     1 M faces, 45 MB of text."""
