@@ -67,3 +67,22 @@ def test_noalloc_deep_tree_and_limits(rt, gpu_ctx):
     assert rc == abi.RT_ERR_INVALID
     rc = gpu_ctx.L.rt_intersect_batch_noalloc(gpu_ctx.h, C.c_void_p(16), (1 << 31), C.c_void_p(16), None)
     assert rc == abi.RT_ERR_TOO_LARGE
+    # Calls on ONE stream are ordered and both answer correctly; a call on ANOTHER stream while the latest one is still running
+    # would share the scratch with it and is refused instead (every kernel of both calls still runs to its normal end).
+    big = random_rays(2_000_000, 4, np.array([0.0, 100.0, -20.0]), 300.0)
+    d_big, d_small = _device_rays(big), _device_rays(rays)
+    h_big = torch.zeros(len(big) * abi.hit_dtype.itemsize, dtype=torch.uint8, device="cuda")
+    h_small = torch.zeros(len(rays) * abi.hit_dtype.itemsize, dtype=torch.uint8, device="cuda")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    L = gpu_ctx.L
+    assert L.rt_intersect_batch_noalloc(gpu_ctx.h, C.c_void_p(d_big.data_ptr()), len(big), C.c_void_p(h_big.data_ptr()), C.c_void_p(s1.cuda_stream)) == abi.RT_OK
+    rc_same = L.rt_intersect_batch_noalloc(gpu_ctx.h, C.c_void_p(d_small.data_ptr()), len(rays), C.c_void_p(h_small.data_ptr()), C.c_void_p(s1.cuda_stream))
+    rc_other = L.rt_intersect_batch_noalloc(gpu_ctx.h, C.c_void_p(d_small.data_ptr()), len(rays), C.c_void_p(h_small.data_ptr()), C.c_void_p(s2.cuda_stream))
+    torch.cuda.synchronize()
+    assert rc_same == abi.RT_OK and rc_other == abi.RT_ERR_INVALID and b"still running" in L.rt_last_error(gpu_ctx.h)
+    assert np.array_equal(h_small.cpu().numpy().view(abi.hit_dtype).view(np.uint8), want.view(np.uint8))
+    # once the stream has drained, another stream may call again
+    assert L.rt_intersect_batch_noalloc(gpu_ctx.h, C.c_void_p(d_small.data_ptr()), len(rays), C.c_void_p(h_small.data_ptr()), C.c_void_p(s2.cuda_stream)) == abi.RT_OK
+    torch.cuda.synchronize()
+    assert np.array_equal(h_small.cpu().numpy().view(abi.hit_dtype).view(np.uint8), want.view(np.uint8))
