@@ -58,6 +58,15 @@ public:
         Check(rt_render(h_, &cam, &o, hdr.data(), nullptr, nullptr, stats));
         return hdr;
     }
+    // One rank's share of a frame: the interleaved tiles with (tile id % tile_world) == tile_rank, written in compact form (3 floats
+    // per owned pixel, rt_tile_pixel_order's order) into DEVICE memory of this context's GPU.  What one of the reference's row-band
+    // threads does (src/DefaultRenderer.cpp:65-71), with a GPU in the thread's place.
+    void RenderTiles(const rt_camera_desc &cam, int tile_size, int tile_rank, int tile_world, float *d_compact_rgb, unsigned seed = 0, rt_stats *stats = nullptr) {
+        rt_render_opts o = rt_render_opts();
+        o.abi_version = RT_ABI_VERSION; o.seed = seed; o.timing = stats ? 1 : 0;
+        o.tile_size = tile_size; o.tile_rank = tile_rank; o.tile_world = tile_world; o.output_on_device = 1; o.compact_output = 1;
+        Check(rt_render(h_, &cam, &o, d_compact_rgb, nullptr, nullptr, stats));
+    }
     void Intersect(const rt_ray *rays, size_t n, rt_hit *hits) const { Check(rt_intersect_batch(h_, rays, n, hits, 0, nullptr)); }
 
     std::vector<unsigned char> EncodeImage(const float *rgb, int nx, int ny, int format) {
@@ -142,19 +151,28 @@ public:
         ctx_.Upload(scene.desc);                                   // RetrieveRenderingParamsFromScene: builds the accelerator
         for (const CameraView &cam : scene.cameras) {
             const std::vector<float> hdr = ctx_.Render(cam.desc);
-            std::vector<unsigned char> file;
-            if (!scene.has_tonemap) file = ctx_.EncodeImage(hdr.data(), cam.desc.nx, cam.desc.ny, RT_IMG_PPM_P3);
-            else {
-                const std::vector<float> mapped = ctx_.Tonemap(hdr.data(), cam.desc.nx, cam.desc.ny, scene.tonemap);
-                file = ctx_.EncodeImage(mapped.data(), cam.desc.nx, cam.desc.ny, RT_IMG_EXR_HALF);
-            }
-            const std::string path = out_dir_ + "/" + cam.image_name;
-            FILE *f = std::fopen(path.c_str(), "wb");
-            if (!f) throw Error(RT_ERR_INVALID, "cannot open " + path);
-            const size_t w = std::fwrite(file.data(), 1, file.size(), f);
-            std::fclose(f);
-            if (w != file.size()) throw Error(RT_ERR_INVALID, "short write to " + path);
+            SaveImage(ctx_, scene, cam, hdr.data(), out_dir_);
         }
+    }
+    // Image::SaveImage for a finished float frame on the host (src/Image.cpp:38-52): P3 text, or HALF EXR after the tone mapper
+    static void SaveImage(Context &ctx, const SceneView &scene, const CameraView &cam, const float *hdr, const std::string &out_dir) {
+        std::vector<unsigned char> file;
+        if (!scene.has_tonemap) file = ctx.EncodeImage(hdr, cam.desc.nx, cam.desc.ny, RT_IMG_PPM_P3);
+        else {
+            const std::vector<float> mapped = ctx.Tonemap(hdr, cam.desc.nx, cam.desc.ny, scene.tonemap);
+            file = ctx.EncodeImage(mapped.data(), cam.desc.nx, cam.desc.ny, RT_IMG_EXR_HALF);
+        }
+        const std::string path = out_dir + "/" + cam.image_name;
+        FILE *f = std::fopen(path.c_str(), "wb");
+        if (!f) throw Error(RT_ERR_INVALID, "cannot open " + path);
+        const size_t w = std::fwrite(file.data(), 1, file.size(), f);
+        std::fclose(f);
+        if (w != file.size()) throw Error(RT_ERR_INVALID, "short write to " + path);
+    }
+    // One rank of a multi-GPU job (one process per GPU): the scene must be uploaded or imported already; renders this rank's tiles of
+    // one camera into the caller's device buffer.  The gather that follows is rt_gather_tiles (rt_mi355_mgpu.h).
+    void RenderCameraTiles(const CameraView &cam, int tile_size, int tile_rank, int tile_world, float *d_compact_rgb) {
+        ctx_.RenderTiles(cam.desc, tile_size, tile_rank, tile_world, d_compact_rgb);
     }
     Context &context() { return ctx_; }
 private:
