@@ -55,6 +55,13 @@ def torus_knot_mesh(n_tris=1_000_000, seed=7, extent=300.0, center=(0.0, 100.0, 
     return pos.astype(F32), faces.astype(np.int64)
 
 
+def dragon_camera(nx=800, ny=480, spp=1):
+    """The camera of dragon_standin_scene at another resolution / sample count, as a camera dict (SceneSoup.camera_desc(0, **it))."""
+    b = SceneBuilder()
+    b.add_lookat_camera((500, -100, 100), (0, 100, -60), (0, 0, 1), 32.0, 1.0, nx, ny, num_samples=spp, image_name="other_dragon.ppm")
+    return dict(b.soup.cameras[0])
+
+
 def dragon_standin_scene(n_tris=1_000_000, nx=800, ny=480, seed=7):
     b = SceneBuilder()
     s = b.soup

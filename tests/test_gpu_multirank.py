@@ -120,3 +120,26 @@ def test_scene_built_once_and_broadcast(tmp_path):
                           "--master-port", "29543", str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "BROADCAST_OK" in out.stdout
+
+
+def test_bench_two_rank_line_carries_both_regimes():
+    """bench.py's N > 1 code path as a two-rank gloo rehearsal on the one GPU (the timing means nothing, the line's shape does): the weak
+    value plus a `strong` object for the fixed 800x480 frame at 1 and 16 spp, and the worst frame_passes / level_syncs of the timed steps."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29545", OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29545", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--tris", "60000",
+                          "--backend", "gloo"], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, out.stdout
+    j = json.loads(line[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and "REHEARSAL" in j["data"] and j["config"]["resolution"] == [1600, 480]
+    assert j["config"]["max_frame_passes"] == 1 and j["config"]["max_level_syncs"] == 0
+    one = None
+    for key in ("spp_1", "spp_16"):
+        s = j["strong"][key]
+        assert s["resolution"] == [800, 480] and s["rays_per_frame"] > 0 and s["value"] > 0 and 0 < s["efficiency"] < 1.5
+        assert s["max_frame_passes"] == 1
+        one = one or s
+    assert j["strong"]["spp_16"]["rays_per_frame"] > 10 * j["strong"]["spp_1"]["rays_per_frame"]
