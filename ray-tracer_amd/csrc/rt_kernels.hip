@@ -878,7 +878,7 @@ struct RenderIO {
     ShadowBuf sb;
     // called once per thread at kernel start: takes the counts from the device; returns the total queue length
     __device__ __forceinline__ int resolve(int, const int *) {
-        if (closest_dev) { const int c = *closest_dev; n_closest = c < n_closest ? c : n_closest; }
+        if (closest_dev) { const int c = *closest_dev; n_closest = c <= n_closest ? c : 0; }      // an outgrown level is not traced (its pass is discarded)
         int ns = 0;
         if (shadow_cap > 0) { ns = *sb.count; ns = ns < shadow_cap ? ns : shadow_cap; }
         return n_closest + ns;
@@ -1409,7 +1409,9 @@ __global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, L
     // Queue space is reserved once per 256-thread block (two atomics per block: same-address atomics from every wave cost
     // ~6 ns each, chip-wide serial).  Inactive threads of the last block take part in the barriers with lit = false, no children.
     __shared__ int s_lit[4], s_child[4], s_refl[4], s_base[2];
-    if (n_dev) { const int c = *n_dev; n = c < n ? c : n; }        // the level's length lives on the device; n is its bound
+    // the level's length lives on the device; n is its capacity.  A counter above the capacity means that the level was outgrown (blocks whose
+    // children did not fit wrote none): the host discards such a pass, so nothing of the level is processed instead of its holes
+    if (n_dev) { const int c = *n_dev; n = c <= n ? c : 0; }
     if ((int)(blockIdx.x * blockDim.x) >= n) return;               // whole block beyond the queue (block-uniform: before any barrier)
     const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i0 < n;
@@ -1597,7 +1599,7 @@ __global__ __launch_bounds__(256) void k_shade_pre(DevScene sc, DevCamera cam, L
 // the children this level spawned, from the child table (block reduction, one atomic per block and kind).
 __global__ __launch_bounds__(256) void k_count_kinds(LevelBuf lv, int n, const int *n_dev, const int *shadow_count, unsigned long long *kind_counts) {
     __shared__ unsigned s_r[4], s_t[4];
-    if (n_dev) { const int c = *n_dev; n = c < n ? c : n; }
+    if (n_dev) { const int c = *n_dev; n = c <= n ? c : 0; }
     unsigned r = 0, t = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int2 ch = lv.child[i];
@@ -1634,7 +1636,7 @@ void rt_launch_count_kinds(hipStream_t s, LevelBuf lv, int n, const int *n_dev, 
 // the background for misses, the texture for replace_all decals.
 __global__ __launch_bounds__(256) void k_shade_post(DevScene sc, DevCamera cam, LevelBuf lv, int n, const int *n_dev, ShadowBuf sb) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n_dev) { const int c = *n_dev; n = c < n ? c : n; }
+    if (n_dev) { const int c = *n_dev; n = c <= n ? c : 0; }
     if (i >= n) return;
     float t;
     const Surf s = load_surf(lv, i, t);
@@ -1683,7 +1685,7 @@ void rt_launch_shade_post(hipStream_t s, const DevScene &sc, const DevCamera &ca
 // Backward sweep: colour(ray) = local + children, in the association order of RecursiveComputation.cpp:62-69,130-141,172-173.
 __global__ __launch_bounds__(256) void k_backward(LevelBuf lv, int n, const int *n_dev, LevelBuf next, int has_next) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n_dev) { const int c = *n_dev; n = c < n ? c : n; }
+    if (n_dev) { const int c = *n_dev; n = c <= n ? c : 0; }
     if (i >= n) return;
     const float4 a = lv.node_a[i];
     const int flags = __float_as_int(a.w);

@@ -80,7 +80,8 @@ void rt_launch_raygen(hipStream_t s, const DevCamera &cam, const int *pixel_list
 // One launch traces lv's closest-hit rays and the shadow queue sb (length on the device, at most shadow_bound; 0 = none).
 // Queue lengths: every launcher takes (n, n_dev).  n_dev == nullptr: the queue holds n entries.  Otherwise the real length is
 // the device counter *n_dev (a level whose size the host never reads back) and n is its upper bound = the capacity the
-// queue was allocated with; the kernels use min(*n_dev, n) and the grid is sized for n.
+// queue was allocated with; the grid is sized for n and the kernels process *n_dev entries — none when *n_dev > n: such a level was
+// outgrown, has holes where blocks could not write their children, and belongs to a pass the host renders again.
 void rt_tl_begin();              // tuning builds: per-launch wave timeline (RT_TIMELINE=1); no-ops otherwise
 void rt_tl_end();
 void rt_launch_trace(hipStream_t s, const DevScene &sc, LevelBuf lv, int n_closest, const int *closest_dev, ShadowBuf sb, int shadow_bound, int *fetch_counter,
