@@ -62,6 +62,7 @@ def main():
                     help="process group of N > 1.  nccl (= RCCL, device tensors) is the measured path; gloo is a rehearsal for boxes with fewer GPUs than "
                          "ranks: all ranks share the GPUs there are, tiles are staged through host memory, and the line is marked as a rehearsal")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-frames-in-flight", action="store_true", help="skip the extra measurement with two frames in flight")
     ap.add_argument("--cpu-row-step", type=int, default=1, help="CPU baseline renders every k-th row of the frame")
     args = ap.parse_args()
 
@@ -308,6 +309,43 @@ def main():
         torch.cuda.synchronize()
         share_ms = {"ms_per_frame": round((time.perf_counter() - t0) * 100.0, 4), "kernels_ms": round(st8.ms_kernels, 4), "rays": int(sum(st8.rays)),
                     "level_syncs": int(st8.level_syncs)}
+    # Throughput with two frames in flight (an animation, or the cameras of one scene): a second context adopts the built scene
+    # (rt_scene_export / rt_scene_import, no second build) and two host threads render the same frame into buffers of their own; one
+    # context's launch tails then overlap the other's launches.  Reported beside `value`, which stays one frame, start to finish.
+    two_in_flight = None
+    if world == 1 and not c5 and not args.no_frames_in_flight:
+        import threading
+        hdr, sizes = ctx.export_scene_header()
+        bufs = [torch.empty(max(nb, 1), dtype=torch.uint8, device=dev) for nb in sizes]
+        for ai, nb in enumerate(sizes):
+            if nb:
+                ctx.export_scene_arena(ai, bufs[ai].data_ptr())
+        ctx2 = rt.Context(local_rank).import_scene(hdr, [b.data_ptr() if nb else 0 for b, nb in zip(bufs, sizes)], soup=soup)
+        del bufs
+        pair = [(ctx, torch.zeros((ny * nx, 3), dtype=torch.float32, device=dev)), (ctx2, torch.zeros((ny * nx, 3), dtype=torch.float32, device=dev))]
+        o_plain = [c.make_opts(seed=0, output_on_device=True) for c, _ in pair]
+        for (c, o), op in zip(pair, o_plain):
+            c.render_device(cd, op, o.data_ptr())            # the imported context's first frame is host-counted
+        per = max(1, args.steps // 2)
+
+        def frames(c, o, op):
+            for _ in range(per):
+                c.render_device(cd, op, o.data_ptr())
+        dt2 = None
+        for _ in range(2):                                   # a warm-up round, then the timed one
+            th = [threading.Thread(target=frames, args=(c, o, op)) for (c, o), op in zip(pair, o_plain)]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t0
+        same = bool(torch.equal(pair[0][1].view(torch.int32), pair[1][1].view(torch.int32)))
+        two_in_flight = {"frames": 2 * per, "ms_per_frame": round(dt2 * 1e3 / (2 * per), 4), "value": round(total_rays * 2 * per / dt2 / 1e6, 2), "unit": "Mrays/s",
+                         "frames_bit_identical": same, "note": "two contexts sharing one built scene, one host thread each; not the headline value"}
+        ctx2.close()
     bvh = ctx.bvh_info()
     out = {"metric": "Mrays/s (primary+secondary, whole node)", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
@@ -320,7 +358,7 @@ def main():
                       "bvh_nodes": int(bvh.n_nodes), "bvh_depth": int(bvh.max_depth), "scene_upload_s": round(upload_s, 2), "kernels_ms_per_frame": round(sum(s.ms_kernels for s in st_steps) / args.steps, 4),
                       "host_round_trips_per_frame": int(st_steps[-1].level_syncs),
                       "max_level_syncs": max_syncs, "max_frame_passes": max_passes, "traversal": "exact (normal-cone pruning rule): hit ids equal the reference's unpruned traversal",
-                      "one_gpu_of_eight_share": share_ms},
+                      "one_gpu_of_eight_share": share_ms, "two_frames_in_flight": two_in_flight},
            "roofline": roofline, "cpu_baseline": cpu}
     if strong_obj is not None:
         out["strong"] = strong_obj
