@@ -14,7 +14,7 @@ trace = [l for l in ks if "k_trace_generic<false, false, RenderIO>" in l][0].spl
 avg_us = float(trace[4])
 open(os.path.join(ROOT, "profiles", rnd + "_bench_kernel_stats.md"), "w").write("""# Round %s — rocprofv3 kernel trace of bench.py, final library of the round (MI355X, 1 GPU)
 
-Command (on the GPU box, tools/profile_round.sh %s): `cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d gpurun_out/%s_kt -o bench -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline`
+Command (on the GPU box, tools/profile_round.sh %s): `cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d gpurun_out/%s_kt -o bench -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-frames-in-flight`
 
 tools/rocpd_summary.py over the `kernels` view of the rocpd database (5 timed + 1 warm-up + 1 counting frame = 7 frames; the
 `<true, ...>` instantiation is the counting frame; the k_bin / k_reduce_boxes / k_split / k_collapse rows are the one-off BVH build
@@ -46,7 +46,7 @@ cyc = c["GRBM_GUI_ACTIVE"] / 8 / frames
 d = dict(cyc=cyc / 1e6, valu=c["SQ_INSTS_VALU"] / frames / 1e9, lanes=c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"],
          wait=100.0 * c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], waiti=100.0 * c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], act=100.0 * c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"],
          l2=100.0 * c["TCC_HIT"] / (c["TCC_HIT"] + c["TCC_MISS"]), ta=100.0 * c["TA_TA_BUSY"] / 256 / (cyc * frames), tas=100.0 * c["TA_ADDR_STALLED_BY_TC_CYCLES"] / 256 / (cyc * frames),
-         acc=c["TCP_TOTAL_CACHE_ACCESSES"] / frames / 1e9, accr=c["TCP_TOTAL_CACHE_ACCESSES"] / frames / rays, vb=100.0 * c["SQ_INSTS_VALU"] * 2 / (1024 * cyc * frames),
+         acc=c["TCP_TOTAL_CACHE_ACCESSES"] / frames / 1e9, accr=c["TCP_TOTAL_CACHE_ACCESSES"] / frames / rays, vb=100.0 * c["SQ_INSTS_VALU"] * 4 / (1024 * cyc * frames),
          fetch=c["FETCH_SIZE"] * 1024 / frames / 1e9, write=c["WRITE_SIZE"] * 1024 / frames / 1e9)
 d["per_launch"] = (2 * d["fetch"] + d["write"]) / 8
 open(os.path.join(ROOT, "profiles", rnd + "_pmc_trace_kernel.md"), "w").write("""# Round %s — hardware counters of the trace kernel (rocprofv3 --pmc, one pass per counter group)
@@ -60,22 +60,22 @@ whose SHA-256 is recorded in profiles/traffic_latest.json (exact traversal with 
 ```
 
 Derived, per frame (tools/profile_docs.py): %.2f M GPU cycles busy; %.2f G wave-level VALU instructions = %.0f %% of the issue slots of 1024 SIMDs
-at 2 cycles per wave64 instruction; active lanes per VALU instruction SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU = %.1f of 64; of the
+at 4 cycles per wave64 instruction (the figure a probe build confirms: 32 extra v_nop per loop iteration, 6.7 %% more instructions, cost 4.5 %% of the trace time); active lanes per VALU instruction SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU = %.1f of 64; of the
 waves' cycles %.0f %% execute instructions, %.0f %% wait for memory counters (SQ_WAIT_ANY), %.0f %% wait for issue (SQ_WAIT_INST_ANY); L2 hit rate
 TCC_HIT / (HIT + MISS) = %.1f %%; vector-cache accesses %.2f G = %.0f per ray (8 per node step + 3 per primitive test);
 texture addresser busy %.0f %% of the launch, stalled by the cache %.0f %%; FETCH_SIZE %.2f GB raw = %.2f GB after the gfx950 correction
 (x2: 128-byte requests are tallied at 64 B) + WRITE_SIZE %.2f GB per frame -> %.2f GB per launch (`roofline.traffic`).
 
-Against the last collection of round 1 (profiles/r01_pmc_trace_kernel.md, pruning without the cone rule): node steps per ray 24.6 -> 32.9
-(+33 %%), VALU instructions 3.06 G per frame then, vector-cache accesses 1.71 G, active lanes 34.4, waves waiting for memory 46 %%, L2 hit 40.7 %%.
+Against the collection of round 2 (profiles/r02_pmc_trace_kernel.md, same exact traversal, 32.9 node steps per ray): 4.37 G VALU instructions
+per frame then, i.e. 640 per loop iteration of a wave against about 475 now (the loop lost its second back edge, loads go through buffer
+descriptors whose range check replaces the zero-initialised merge registers, the unit-matrix object ray is prepared at refill).
 
-An experiment suggested by the addresser numbers — node records fetched by quads of lanes, one 64-byte request per half record and two
-DPP 4x4 transposes, 4x fewer cache requests for nodes — was bit-identical and 9 %% slower (1 spp) / 10 %% slower (16 spp): the cache's
-address rate is not the limiter.  tools/size_sweep.sh: the trace time per ray and node step is the same (26.4 ... 27.3 ps) for scenes of
-62 k to 4 M triangles, i.e. independent of the cache footprint.  The loop is bound by the per-wave serial chain (about 700 VALU + 160
-scalar instructions and one memory round trip per iteration, 4 waves per SIMD at 128 VGPRs and 39 KB LDS per block).
+What limits the kernel: VALU instruction issue at about half the lanes active.  A wave iteration is one node step for the lanes at a node
+(45 of 64 on average) plus, in 73 %% of the iterations, one primitive test for the lanes that hold a pending leaf (14 of 64); the last fifth
+of all iterations runs after a launch's queue is empty, at 33 of 64 lanes.  The memory side is loaded but not at its limit: HBM traffic %.2f GB per launch is about 40 %% of the 8 TB/s peak over the launch's duration,
+the texture addresser is busy 64 %% of the time, and the time per node step does not depend on the scene's footprint (tools/size_sweep.sh).
 """ % (rnd[1:], tag, blk.strip(), d["cyc"], d["valu"], d["vb"], d["lanes"], d["act"], d["wait"], d["waiti"], d["l2"], d["acc"], d["accr"], d["ta"], d["tas"],
-       d["fetch"], 2 * d["fetch"], d["write"], d["per_launch"]))
+       d["fetch"], 2 * d["fetch"], d["write"], d["per_launch"], d["per_launch"]))
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "traffic_json.py"), os.path.join(G, tag + "_pmc"), "2"])
 if len(sys.argv) > 3:
     xs = open(os.path.join(G, sys.argv[3] + "_summary.txt")).read()
@@ -95,8 +95,7 @@ if len(sys.argv) > 3:
 
 Per frame: %.2f G instruction fetches, instruction-cache misses %.0f k (the 18 KB loop stays resident), LDS bank conflicts %.1f M cycles against
 %.0f M cycles of LDS activity, waves waiting for the LDS %.1f %% of their cycles, scalar instructions %.2f G (%.2f per VALU instruction).
-No unit is saturated: VALU %.0f %%, texture addresser %.0f %%, scalar and LDS far below; together with the footprint-independent time per
-node step this is what "bound by the per-wave serial chain at four waves per SIMD" rests on.
+VALU issue %.0f %% of the SIMD cycles, texture addresser %.0f %%, scalar and LDS far below: the vector ALU's issue slots are what the loop runs out of.
 """ % (xb.strip(), x["SQ_IFETCH"] / frames / 1e9, x["SQC_ICACHE_MISSES"] / frames / 1e3, x["SQ_LDS_BANK_CONFLICT"] / frames / 1e6, x["SQ_LDS_IDX_ACTIVE"] / frames / 1e6,
        100.0 * x["SQ_WAIT_INST_LDS"] / c["SQ_WAVE_CYCLES"], x["SQ_INST_CYCLES_SALU"] / frames / 1e9, x["SQ_INST_CYCLES_SALU"] / c["SQ_INSTS_VALU"], d["vb"], d["ta"]))
 if len(sys.argv) > 4:
