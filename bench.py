@@ -262,10 +262,10 @@ def main():
                 survey["frac_fp32_valu_157"] = round(sflops / (trace_ms * 1e-3) / 1e12 / 157.0, 5)
         except Exception:
             survey = None
-    # "bound": the contract's two choices are hbm and mfma; the kernel is neither (no matrix work, and HBM moves a few percent of its
-    # peak): it is bound by VALU instruction issue at ~50 % active lanes (v_nop probe).  "hbm" names the yardstick `achieved` and
-    # `frac` are measured on, `limited_by` names what limits the kernel; traffic_frac = measured HBM bytes / launch time / peak.
-    roofline = {"bound": "hbm", "limited_by": "VALU issue (divergent wave64 traversal); HBM traffic is far below peak",
+    # "bound": of the contract's two choices (hbm, mfma) hbm is the one that applies: there is no matrix work.  The kernel does not reach that
+    # roof: measured HBM traffic is about 40 % of peak while VALU instruction issue is at 75-90 % with half the lanes active (counter passes and
+    # v_nop probe).  `achieved` / `frac` price the ALGORITHMIC bytes; traffic_frac = measured HBM bytes / launch time / peak.
+    roofline = {"bound": "hbm", "limited_by": "VALU instruction issue of the divergent wave64 traversal (about half the lanes active); measured HBM traffic is ~40 % of peak",
                 "traffic_frac": (round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None),
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic, "kernel": "k_trace_generic (closest-hit rays of a level + shadow rays of the level before, one launch)", "launches_per_frame": launches,
