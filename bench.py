@@ -267,6 +267,8 @@ def main():
     # v_nop probe).  `achieved` / `frac` price the ALGORITHMIC bytes; traffic_frac = measured HBM bytes / launch time / peak.
     roofline = {"bound": "hbm", "limited_by": "VALU instruction issue of the divergent wave64 traversal (about half the lanes active); measured HBM traffic is ~40 % of peak",
                 "traffic_frac": (round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None),
+                "achieved_is": "a model: counted node steps and primitive tests x the record bytes each reads (the node's cone words, a 16-byte piece only lanes "
+                               "with a bound load, are not counted), not measured traffic; traffic / traffic_frac are the measured HBM bytes",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic, "kernel": "k_trace_generic (closest-hit rays of a level + shadow rays of the level before, one launch)", "launches_per_frame": launches,
                 "avg_launch_ms": round(avg_launch_ms, 5), "algorithmic_bytes_per_launch": round(bytes_per_launch),
