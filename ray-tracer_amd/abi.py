@@ -86,7 +86,7 @@ class RenderOpts(C.Structure):
         ("abi_version", C.c_uint32), ("seed", C.c_uint32), ("tile_size", C.c_int32), ("tile_rank", C.c_int32),
         ("tile_world", C.c_int32), ("output_on_device", C.c_int32), ("compact_output", C.c_int32),
         ("max_batch_samples", C.c_int32), ("timing", C.c_int32), ("num_streams", C.c_int32), ("level_counts", C.c_int32),
-        ("_reserved", C.c_int32)]
+        ("shadow_stream", C.c_int32)]
 
 
 class Stats(C.Structure):

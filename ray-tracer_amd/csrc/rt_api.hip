@@ -119,8 +119,13 @@ struct StreamLane {
         }
         void release() { o.release(); d.release(); ip.release(); ldir.release(); occ.release(); }
     } sh[2];                                // shadow rays of level k live in sh[k & 1] until level k+1's launch has traced them
-    DevArray<int> d_counts;                 // [child counts | fetch counters | - | shadow queue lengths] x (max_depth+2)
+    DevArray<int> d_counts;                 // [child counts | fetch counters | refraction children | shadow queue lengths | fetch counters of the shadow launches] x (max_depth+2)
     DevArray<int> d_overflow;
+    // Shadow rays and the lighting that needs them run beside the closest-hit chain, on a stream of their own (frames whose level
+    // lengths stay on the device): the chain of a frame is trace -> surface pass -> trace of the children, the shadow rays hang off it.
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ev_pre, ev_post;   // surface pass of level k done (main stream) / lighting of level k done (side stream)
+    DevArray<int> d_overflow_side;
     // state of the batch in flight
     bool busy = false;
     int64_t p0 = 0;
@@ -128,7 +133,12 @@ struct StreamLane {
     void release() {
         for (auto &l : levels) l.release();
         levels.clear();
-        sh[0].release(); sh[1].release(); d_counts.release(); d_overflow.release();
+        sh[0].release(); sh[1].release(); d_counts.release(); d_overflow.release(); d_overflow_side.release();
+        for (hipEvent_t e : ev_pre) if (e) hipEventDestroy(e);
+        for (hipEvent_t e : ev_post) if (e) hipEventDestroy(e);
+        ev_pre.clear(); ev_post.clear();
+        if (side) hipStreamDestroy(side);
+        side = nullptr;
         if (h_count) hipHostFree(h_count);
         if (ev_count) hipEventDestroy(ev_count);
         if (ev_done) hipEventDestroy(ev_done);
@@ -660,9 +670,21 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
     n_streams = (int)std::max<int64_t>(1, std::min<int64_t>(n_streams, (n_owned + batch_pixels - 1) / batch_pixels));
     if ((int)c->lanes.size() < n_streams) c->lanes.resize(n_streams);
     if (!c->ev_ready) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
-    const size_t n_cnt = 4 * ((size_t)max_depth + 2);
+    const size_t n_cnt = 5 * ((size_t)max_depth + 2);
+    const bool side_shadows = opts->shadow_stream == 1 && nl > 0;
     for (int j = 0; j < n_streams; ++j) {
         StreamLane &ln = c->lanes[j];
+        if (side_shadows) {
+            if (!ln.side) HIP_TRY(c, hipStreamCreateWithFlags(&ln.side, hipStreamNonBlocking));
+            while ((int)ln.ev_pre.size() < max_depth + 2) {
+                hipEvent_t a = nullptr, b = nullptr;
+                HIP_TRY(c, hipEventCreateWithFlags(&a, hipEventDisableTiming));
+                ln.ev_pre.push_back(a);
+                HIP_TRY(c, hipEventCreateWithFlags(&b, hipEventDisableTiming));
+                ln.ev_post.push_back(b);
+            }
+            HIP_TRY(c, ln.d_overflow_side.ensure((size_t)std::max(1, c->overflow_depth) * rt_trace_grid_threads()));
+        }
         if (!ln.stream) {
             HIP_TRY(c, hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
             HIP_TRY(c, hipEventCreateWithFlags(&ln.ev_count, hipEventDisableTiming));
@@ -715,6 +737,11 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
         auto ndev = [&](int k) -> const int * { return dev && k > 0 ? counts + k : nullptr; };
         const ShadowBuf sb = shadow_view(ln, counts, last);
         const int bound = shadow_bound(ln, last);
+        if (dev && side_shadows) {
+            // every level's shadow rays and lighting were queued on the side stream by enqueue_level: the backward sweep needs them all
+            // (the side stream runs them in level order, so its last event covers the earlier ones)
+            HIP_TRY(c, hipStreamWaitEvent(st, ln.ev_post[(size_t)last], 0));
+        } else {
         if (bound > 0) {
             int rc = timed_trace(st, [&] { rt_launch_trace(st, c->dev, ln.levels[last].view(), 0, nullptr, sb, bound, counts + (max_depth + 2) + last + 1, ln.d_overflow.p, d_counters); });
             if (rc != RT_OK) return rc;
@@ -722,6 +749,7 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
             if (!dev) trace_rays += (uint64_t)bound;
         }
         rt_launch_shade_post(st, c->dev, dc, ln.levels[last].view(), ln.levels[last].count, ndev(last), sb);
+        }
         for (int k = last; k >= 0; --k)
             rt_launch_backward(st, ln.levels[k].view(), ln.levels[k].count, ndev(k), ln.levels[k + 1].view(), (k < last) ? 1 : 0);
         rt_launch_resolve(st, dc, c->d_pixels.p, (int)ln.p0, ln.np, ln.levels[0].view(), compact ? 1 : 0, d_hdr, d_pid, d_pt);
@@ -737,8 +765,9 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
         LevelMem &lm = ln.levels[k];
         const int n = lm.count;
         auto ndev = [&](int q) -> const int * { return dev && q > 0 ? counts + q : nullptr; };
+        const bool split = dev && side_shadows;      // the shadow rays of this level get a launch of their own, on the side stream
         const ShadowBuf sb_prev = shadow_view(ln, counts, k > 0 ? k - 1 : 1);
-        const int bound_prev = k > 0 ? shadow_bound(ln, k - 1) : 0;
+        const int bound_prev = (k > 0 && !split) ? shadow_bound(ln, k - 1) : 0;
         int rc = timed_trace(st, [&] { rt_launch_trace(st, c->dev, lm.view(), n, ndev(k), sb_prev, bound_prev, counts + (max_depth + 2) + k, ln.d_overflow.p, d_counters); });
         if (rc != RT_OK) return rc;
         ++trace_launches;
@@ -756,7 +785,23 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
             }
             nxv = nx.view();
         } else { nxv = nx.view(); nxv.capacity = next_cap; }     // buffers were sized before the batch started
+        // the surface pass of level k writes the shadow queue sh[k & 1]: the lighting of level k-2, which read it last, must be done
+        if (split && k >= 2) HIP_TRY(c, hipStreamWaitEvent(st, ln.ev_post[(size_t)k - 2], 0));
         rt_launch_shade_pre(st, c->dev, dc, lm.view(), n, ndev(k), shadow_view(ln, counts, k), nxv, k, counts + k + 1, counts + 2 * (max_depth + 2) + k);
+        if (split) {
+            const ShadowBuf sb_k = shadow_view(ln, counts, k);
+            const int bound_k = shadow_bound(ln, k);
+            HIP_TRY(c, hipEventRecord(ln.ev_pre[(size_t)k], st));
+            HIP_TRY(c, hipStreamWaitEvent(ln.side, ln.ev_pre[(size_t)k], 0));
+            if (bound_k > 0) {
+                rc = timed_trace(ln.side, [&] { rt_launch_trace(ln.side, c->dev, lm.view(), 0, nullptr, sb_k, bound_k, counts + 4 * (max_depth + 2) + k, ln.d_overflow_side.p, d_counters); });
+                if (rc != RT_OK) return rc;
+                ++trace_launches;
+            }
+            rt_launch_shade_post(ln.side, c->dev, dc, lm.view(), n, ndev(k), sb_k);
+            HIP_TRY(c, hipEventRecord(ln.ev_post[(size_t)k], ln.side));
+            return RT_OK;
+        }
         if (!dev && k < max_depth) {
             HIP_TRY(c, hipMemcpyAsync(ln.h_count, counts + k + 1, sizeof(int), hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipEventRecord(ln.ev_count, st));
@@ -1001,7 +1046,10 @@ int rt_render(rt_ctx *c, const rt_camera_desc *cam, const rt_render_opts *opts, 
     }
     if (frc != RT_OK) {
         // leave no launch of a failed frame in flight: they write caller-owned buffers and the context's queues
-        for (int j = 0; j < n_streams; ++j) if (c->lanes[j].stream) hipStreamSynchronize(c->lanes[j].stream);
+        for (int j = 0; j < n_streams; ++j) {
+            if (c->lanes[j].side) hipStreamSynchronize(c->lanes[j].side);
+            if (c->lanes[j].stream) hipStreamSynchronize(c->lanes[j].stream);
+        }
         hipStreamSynchronize(s);
         return frc;
     }

@@ -190,13 +190,14 @@ class Context:
         return info
 
     def make_opts(self, seed=0, tile_size=0, tile_rank=0, tile_world=1, output_on_device=False, compact_output=False,
-                  max_batch_samples=0, timing=0, num_streams=0, level_counts=0):
+                  max_batch_samples=0, timing=0, num_streams=0, level_counts=0, shadow_stream=0):
         o = abi.RenderOpts()
         o.abi_version = abi.RT_ABI_VERSION
         o.seed, o.tile_size, o.tile_rank, o.tile_world = seed, tile_size, tile_rank, tile_world
         o.output_on_device, o.compact_output = int(output_on_device), int(compact_output)
         o.max_batch_samples, o.timing, o.num_streams = max_batch_samples, int(timing), int(num_streams)
         o.level_counts = int(level_counts)      # 1: the host reads every level's length (rt_render_opts.level_counts)
+        o.shadow_stream = int(shadow_stream)    # 1: shadow rays and lighting on a second stream beside the closest-hit chain
         return o
 
     def render(self, cam=0, want_ids=True, **kw):

@@ -200,3 +200,39 @@ def test_frames_after_the_first_make_no_host_round_trip(rt, orc, gpu_ctx, scene_
     compare_frames(h6, c_hdr, i1, c_id, t1, c_t)
     assert list(s6.rays) == list(c_st.rays) and s6.rays[rt.abi.RT_RAY_REFRACT] > 0
     assert list(s6.rays) == list(c_st.rays)
+
+
+def test_shadow_rays_on_a_stream_of_their_own(rt, gpu_ctx, scene_path):
+    """rt_render_opts.shadow_stream = 1: in frames whose level lengths stay on the device the shadow rays of a level and the lighting
+    that needs them run on a second stream beside the closest-hit chain (14 trace launches instead of 8 fused ones for depth 6).  Frames,
+    hit ids, ray counts: bit for bit those of the fused launches — one batch, several batches on two streams, area lights + glossy
+    (random numbers keyed per ray), and a frame whose prediction fails (second pass, host-counted, fused)."""
+    for name, n in (("cornellbox_recursive", 200), ("cornellbox_brushed_metal", 96), ("scienceTree", 160)):
+        soup = rt.SceneSoup.load(scene_path(name))
+        for c in soup.cameras:
+            c["num_samples"] = min(int(c.get("num_samples", 1)), 4)
+        gpu_ctx.upload(soup)
+        h0, i0, t0, s0 = gpu_ctx.render(0, nx=n, ny=n, timing=1)                    # first frame: host-counted
+        h1, i1, t1, s1 = gpu_ctx.render(0, nx=n, ny=n, timing=1)                    # predicted, fused
+        h2, i2, t2, s2 = gpu_ctx.render(0, nx=n, ny=n, timing=1, shadow_stream=1)   # predicted, side stream
+        assert s1.level_syncs == 0 and s2.level_syncs == 0 and s2.frame_passes == 1
+        assert s2.trace_launches > s1.trace_launches
+        for h, i, t, st in ((h1, i1, t1, s1), (h2, i2, t2, s2)):
+            assert np.array_equal(h.view(np.uint32), h0.view(np.uint32)) and np.array_equal(i, i0) and np.array_equal(t.view(np.uint32), t0.view(np.uint32))
+            assert list(st.rays) == list(s0.rays)
+        h3, _, _, s3 = gpu_ctx.render(0, nx=n, ny=n, max_batch_samples=5000, num_streams=2, shadow_stream=1)
+        assert s3.level_syncs == 0 and np.array_equal(h3.view(np.uint32), h0.view(np.uint32)) and list(s3.rays) == list(s0.rays)
+        h4, _, _, s4 = gpu_ctx.render(0, nx=n, ny=n, max_batch_samples=3000, num_streams=1, shadow_stream=1)      # several batches, one after the other, on one lane
+        assert np.array_equal(h4.view(np.uint32), h0.view(np.uint32)) and list(s4.rays) == list(s0.rays)
+    # a failed prediction with the side stream on: the second pass repairs it
+    soup = rt.SceneSoup.load(scene_path("cornellbox_recursive"))
+    gpu_ctx.upload(soup)
+    h1 = gpu_ctx.render(0, nx=200, ny=200)[0]
+    cd = soup.camera_desc(0, nx=200, ny=200)
+    away = type(cd).from_buffer_copy(cd)
+    away.gaze[0], away.gaze[1], away.gaze[2] = 0.0, 0.0, 1.0
+    gpu_ctx.render(away, shadow_stream=1)
+    h5, _, _, s5 = gpu_ctx.render(0, nx=200, ny=200, shadow_stream=1)
+    assert s5.frame_passes == 2 and np.array_equal(h5.view(np.uint32), h1.view(np.uint32))
+    h6, _, _, s6 = gpu_ctx.render(0, nx=200, ny=200, shadow_stream=1)
+    assert s6.frame_passes == 1 and s6.level_syncs == 0 and np.array_equal(h6.view(np.uint32), h1.view(np.uint32))
