@@ -1,5 +1,5 @@
 #!/bin/bash
-# one counter pass (instruction counts, lanes, waits) over the config-2 driver.  usage: tools/r03_pmc1.sh <tag>
+# one counter pass (instruction counts, lanes, waits) over the config-2 driver.  usage: tools/pmc_quick.sh <tag>
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/${1:-pmc1}
 mkdir -p "$OUT"
