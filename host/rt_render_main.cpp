@@ -1,6 +1,7 @@
 // rt_render — the reference's main (src/main.cpp:15-30) over the MI355X path, in the reference's language:
 //   parse the scene (here: the flat scene file, host/scene_file.h), create the renderer, RenderSceneIntoPPM, report the time.
 // usage: rt_render <scene.rtscene> [out_dir] [--rays <rays.bin> <hits.bin>] [--shared-scene] [--ranks N] [--tile T]
+//   --in-flight K: the cameras of the scene are rendered by K contexts sharing one built scene, one host thread each (default 1).
 //   --ranks N: render every frame on GPUs 0..N-1 of this process (interleaved T x T tiles, default 32; scene built on GPU 0 and broadcast,
 //              tiles gathered on GPU 0 over RCCL: include/rt_mi355_mgpu.hpp) instead of on GPU 0 alone.  Same files either way.
 //   --rays: also answer a batch of AccelerationStructure::Intersect queries (rt_ray records in, rt_hit records out).
@@ -16,19 +17,20 @@
 #include "rt_mi355_mgpu.hpp"
 
 int main(int argc, char **argv) {
-    if (argc < 2) { std::fprintf(stderr, "usage: %s <scene.rtscene> [out_dir] [--rays rays.bin hits.bin] [--shared-scene] [--ranks N] [--tile T]\n", argv[0]); return 2; }
+    if (argc < 2) { std::fprintf(stderr, "usage: %s <scene.rtscene> [out_dir] [--rays rays.bin hits.bin] [--shared-scene] [--in-flight K] [--ranks N] [--tile T]\n", argv[0]); return 2; }
     try {
         rt_mi355::LoadedScene scene;
         rt_mi355::LoadScene(argv[1], scene);
         std::string out_dir = ".";
         const char *rays_path = nullptr, *hits_path = nullptr;
         bool shared_scene = false;
-        int ranks = 0, tile = 32;
+        int ranks = 0, tile = 32, in_flight = 1;
         for (int i = 2; i < argc; ++i) {
             if (!std::strcmp(argv[i], "--rays") && i + 2 < argc) { rays_path = argv[i + 1]; hits_path = argv[i + 2]; i += 2; }
             else if (!std::strcmp(argv[i], "--shared-scene")) shared_scene = true;
             else if (!std::strcmp(argv[i], "--ranks") && i + 1 < argc) ranks = std::atoi(argv[++i]);
             else if (!std::strcmp(argv[i], "--tile") && i + 1 < argc) tile = std::atoi(argv[++i]);
+            else if (!std::strcmp(argv[i], "--in-flight") && i + 1 < argc) in_flight = std::atoi(argv[++i]);
             else out_dir = argv[i];
         }
         if (ranks > 0) {
@@ -43,7 +45,7 @@ int main(int argc, char **argv) {
                         scene.view.cameras.size(), argv[1], ranks, tile, tile, ms, (long long)info.n_nodes, info.max_depth);
             return 0;
         }
-        rt_mi355::Mi355Renderer renderer(0, out_dir);                   // main.cpp:20  new DefaultRenderer()
+        rt_mi355::Mi355Renderer renderer(0, out_dir, in_flight);                   // main.cpp:20  new DefaultRenderer()
         const auto t0 = std::chrono::steady_clock::now();
         renderer.RenderSceneIntoPPM(scene.view);                          // main.cpp:22
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -13,10 +13,14 @@
 #ifndef RT_MI355_HPP_
 #define RT_MI355_HPP_
 
+#include <atomic>
 #include <cstdio>
+#include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
+#include <algorithm>
 
 #include "rt_mi355.h"
 
@@ -146,13 +150,41 @@ private:
 // Image::SaveImageAsPPM, or with <Tonemap> the tone-mapped frame as HALF EXR (Image::SaveImage, src/Image.cpp:38-52).
 class Mi355Renderer {
 public:
-    explicit Mi355Renderer(int hip_device = 0, const std::string &out_dir = ".") : ctx_(hip_device), out_dir_(out_dir) {}
+    // frames_in_flight = 2: the cameras of a scene are rendered by two contexts that share one built scene (ExportScene / ImportScene),
+    // one host thread each, so that one context's launch tails overlap the other's launches.  The files are the same either way.
+    explicit Mi355Renderer(int hip_device = 0, const std::string &out_dir = ".", int frames_in_flight = 1)
+        : ctx_(hip_device), device_(hip_device), out_dir_(out_dir), in_flight_(frames_in_flight < 1 ? 1 : frames_in_flight) {}
     void RenderSceneIntoPPM(const SceneView &scene) {
         ctx_.Upload(scene.desc);                                   // RetrieveRenderingParamsFromScene: builds the accelerator
-        for (const CameraView &cam : scene.cameras) {
-            const std::vector<float> hdr = ctx_.Render(cam.desc);
-            SaveImage(ctx_, scene, cam, hdr.data(), out_dir_);
+        const size_t n_ctx = std::min<size_t>((size_t)in_flight_, scene.cameras.size());
+        if (n_ctx <= 1) {
+            for (const CameraView &cam : scene.cameras) {
+                const std::vector<float> hdr = ctx_.Render(cam.desc);
+                SaveImage(ctx_, scene, cam, hdr.data(), out_dir_);
+            }
+            return;
         }
+        std::vector<std::unique_ptr<Context> > extra;
+        {
+            const Context::SceneBytes built = ctx_.ExportScene();
+            for (size_t i = 1; i < n_ctx; ++i) { extra.emplace_back(new Context(device_)); extra.back()->ImportScene(built); }
+        }
+        std::atomic<size_t> next(0);
+        std::vector<std::string> failed(n_ctx);
+        std::vector<int> code(n_ctx, RT_OK);
+        std::vector<std::thread> workers;
+        for (size_t w = 0; w < n_ctx; ++w)
+            workers.emplace_back([&, w] {
+                Context &ctx = w == 0 ? ctx_ : *extra[w - 1];
+                try {
+                    for (size_t i = next++; i < scene.cameras.size(); i = next++) {
+                        const std::vector<float> hdr = ctx.Render(scene.cameras[i].desc);
+                        SaveImage(ctx, scene, scene.cameras[i], hdr.data(), out_dir_);
+                    }
+                } catch (const Error &e) { code[w] = e.code; failed[w] = e.what(); }
+            });
+        for (std::thread &t : workers) t.join();
+        for (size_t w = 0; w < n_ctx; ++w) if (code[w] != RT_OK) throw Error(code[w], failed[w]);
     }
     // Image::SaveImage for a finished float frame on the host (src/Image.cpp:38-52): P3 text, or HALF EXR after the tone mapper
     static void SaveImage(Context &ctx, const SceneView &scene, const CameraView &cam, const float *hdr, const std::string &out_dir) {
@@ -177,7 +209,9 @@ public:
     Context &context() { return ctx_; }
 private:
     Context ctx_;
+    int device_;
     std::string out_dir_;
+    int in_flight_;
 };
 
 }  // namespace rt_mi355

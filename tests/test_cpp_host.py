@@ -81,3 +81,36 @@ def test_cpp_host_tonemap_exr(rt, scene_path, tmp_path):
     data = open(cdir / name, "rb").read()
     assert data[:4] == bytes([0x76, 0x2f, 0x31, 0x01]) and data == open(pdir / name, "rb").read()
     r.close()
+
+
+@pytest.mark.gpu
+def test_cameras_in_flight_write_the_same_files(rt, scene_path, tmp_path):
+    """A scene with several cameras rendered with two frames in flight (two contexts that share one built scene, a host thread each) —
+    Python mirror and C++ host — writes byte for byte the files the one-context loop writes."""
+    soup = rt.SceneSoup.load(scene_path("cornellbox_recursive"))
+    base = dict(soup.cameras[0])
+    base["nx"], base["ny"], base["num_samples"] = 120, 90, 1
+    soup.cameras = []
+    for k in range(5):                                       # five views: the camera slides sideways
+        c = dict(base)
+        c["position"] = [float(base["position"][0]) + 0.6 * (k - 2), float(base["position"][1]), float(base["position"][2])]
+        c["image_name"] = "view_%d.ppm" % k
+        soup.cameras.append(c)
+    soup.save_raw(str(tmp_path / "s.rtscene"))
+    dirs = {}
+    for name in ("py1", "py2", "cpp1", "cpp2"):
+        dirs[name] = tmp_path / name
+        dirs[name].mkdir()
+    for name, k in (("py1", 1), ("py2", 2)):
+        r = rt.Mi355Renderer(0, out_dir=str(dirs[name]), frames_in_flight=k)
+        r.RenderSceneIntoPPM(soup)
+        assert len(r.frames) == 5
+        r.close()
+    for name, k in (("cpp1", 1), ("cpp2", 2)):
+        out = _run([str(tmp_path / "s.rtscene"), str(dirs[name]), "--in-flight", str(k)])
+        assert out.returncode == 0, out.stderr
+    ref = {c["image_name"]: open(dirs["py1"] / c["image_name"], "rb").read() for c in soup.cameras}
+    assert len(set(ref.values())) == 5                       # the views differ
+    for name in ("py2", "cpp1", "cpp2"):
+        for f, data in ref.items():
+            assert open(dirs[name] / f, "rb").read() == data, (name, f)
