@@ -45,6 +45,7 @@ int rt_gather_create_rank(const void *id_bytes, int rank, int world, int hip_dev
  *               tile_rank = that rank, tile_world = world, compact_output = 1, output_on_device = 1; 3 floats per owned pixel.
  *               One process with N GPUs passes N pointers (rank order), one process per GPU passes one.
  *   d_frame     on rank 0 only (NULL elsewhere): ny * nx * 3 floats in rank 0's device memory, row-major.
+ * The tile buffers must be complete when the call is made (rt_render has returned: it waits for its stream).
  * Blocking: returns when rank 0's frame is complete (other ranks: when their send has been handed over). */
 int rt_gather_tiles(rt_gather *g, int nx, int ny, int tile_size, const float *const *d_tiles, float *d_frame);
 

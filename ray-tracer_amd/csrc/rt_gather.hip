@@ -49,6 +49,10 @@ struct rt_gather {
 #define G_NCCL(g, expr)                                                                             \
     do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { (g)->error = std::string(#expr) + ": " + ncclGetErrorString(r_); return RT_ERR_HIP; } } while (0)
 
+// Inside ncclGroupStart / ncclGroupEnd a failed call must not leave the group open: remember the first failure, keep going to the
+// group's end, report afterwards.
+#define G_NCCL_IN_GROUP(first, expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess && (first) == ncclSuccess) (first) = r_; } while (0)
+
 // out[order[i]] = in[i] for the concatenated tile buffers: entries [0, n0) come from rank 0's own buffer, the rest from the staging area
 __global__ void k_deinterleave(const float *own, const float *stage, const int *order, long long n0, long long n, float *frame) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -251,20 +255,22 @@ int rt_gather_tiles(rt_gather *g, int nx, int ny, int tile_size, const float *co
     for (size_t i = 0; i < g->local.size(); ++i)
         if (g->count[(size_t)g->local[i].rank] > 0 && !d_tiles[i]) { g->error = "rt_gather_tiles: NULL tile buffer"; return RT_ERR_INVALID; }
     // every peer sends its compact buffer to rank 0; rank 0 posts the matching receives (one group: the transfers run side by side)
+    ncclResult_t first = ncclSuccess;
     G_NCCL(g, ncclGroupStart());
     for (size_t i = 0; i < g->local.size(); ++i) {
         const Local &l = g->local[i];
         if (l.rank != 0 && g->count[(size_t)l.rank] > 0)
-            G_NCCL(g, ncclSend(d_tiles[i], 3 * (size_t)g->count[(size_t)l.rank], ncclFloat, 0, l.comm, l.stream));
+            G_NCCL_IN_GROUP(first, ncclSend(d_tiles[i], 3 * (size_t)g->count[(size_t)l.rank], ncclFloat, 0, l.comm, l.stream));
     }
     if (root) {
         size_t at = 0;
         for (int r = 1; r < g->world; ++r) {
-            if (g->count[(size_t)r] > 0) G_NCCL(g, ncclRecv(g->d_stage + at, 3 * (size_t)g->count[(size_t)r], ncclFloat, r, root->comm, root->stream));
+            if (g->count[(size_t)r] > 0) G_NCCL_IN_GROUP(first, ncclRecv(g->d_stage + at, 3 * (size_t)g->count[(size_t)r], ncclFloat, r, root->comm, root->stream));
             at += 3 * (size_t)g->count[(size_t)r];
         }
     }
     G_NCCL(g, ncclGroupEnd());
+    if (first != ncclSuccess) { g->error = std::string("rt_gather_tiles: ncclSend / ncclRecv: ") + ncclGetErrorString(first); return RT_ERR_HIP; }
     if (root) {
         size_t root_slot = 0;
         for (size_t i = 0; i < g->local.size(); ++i) if (g->local[i].rank == 0) root_slot = i;
@@ -312,9 +318,11 @@ int rt_scene_broadcast(rt_gather *g, rt_ctx *const *ctxs) {
         if (tmp.alloc(g->local[i].device, meta_bytes, (void **)&d_meta[i]) != RT_OK) { g->error = "rt_scene_broadcast: out of device memory"; return RT_ERR_HIP; }
         if (g->local[i].rank == 0) G_HIP(g, hipMemcpyAsync(d_meta[i], meta.data(), meta_bytes, hipMemcpyHostToDevice, g->local[i].stream));
     }
+    ncclResult_t first = ncclSuccess;
     G_NCCL(g, ncclGroupStart());
-    for (size_t i = 0; i < g->local.size(); ++i) G_NCCL(g, ncclBroadcast(d_meta[i], d_meta[i], meta_bytes, ncclUint8, 0, g->local[i].comm, g->local[i].stream));
+    for (size_t i = 0; i < g->local.size(); ++i) G_NCCL_IN_GROUP(first, ncclBroadcast(d_meta[i], d_meta[i], meta_bytes, ncclUint8, 0, g->local[i].comm, g->local[i].stream));
     G_NCCL(g, ncclGroupEnd());
+    if (first != ncclSuccess) { g->error = std::string("rt_scene_broadcast: ncclBroadcast: ") + ncclGetErrorString(first); return RT_ERR_HIP; }
     std::vector<std::vector<unsigned char> > metas(g->local.size(), std::vector<unsigned char>(meta_bytes));
     for (size_t i = 0; i < g->local.size(); ++i) {
         G_HIP(g, hipSetDevice(g->local[i].device));
@@ -338,8 +346,9 @@ int rt_scene_broadcast(rt_gather *g, rt_ctx *const *ctxs) {
         if (rc_all != RT_OK) break;
         G_NCCL(g, ncclGroupStart());
         for (size_t i = 0; i < g->local.size(); ++i)
-            G_NCCL(g, ncclBroadcast(bufs[i][(size_t)a], bufs[i][(size_t)a], (size_t)sizes[a], ncclUint8, 0, g->local[i].comm, g->local[i].stream));
+            G_NCCL_IN_GROUP(first, ncclBroadcast(bufs[i][(size_t)a], bufs[i][(size_t)a], (size_t)sizes[a], ncclUint8, 0, g->local[i].comm, g->local[i].stream));
         G_NCCL(g, ncclGroupEnd());
+        if (first != ncclSuccess) { g->error = std::string("rt_scene_broadcast: ncclBroadcast: ") + ncclGetErrorString(first); return RT_ERR_HIP; }
     }
     for (size_t i = 0; i < g->local.size(); ++i) { G_HIP(g, hipSetDevice(g->local[i].device)); G_HIP(g, hipStreamSynchronize(g->local[i].stream)); }
     // 3. every other rank adopts the bytes
