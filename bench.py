@@ -263,8 +263,8 @@ def main():
         except Exception:
             survey = None
     # "bound": of the contract's two choices (hbm, mfma) hbm is the one that applies: there is no matrix work.  The kernel does not reach that
-    # roof: measured HBM traffic is about 40 % of peak while VALU instruction issue is at 75-90 % with half the lanes active (counter passes and
-    # v_nop probe).  `achieved` / `frac` price the ALGORITHMIC bytes; traffic_frac = measured HBM bytes / launch time / peak.
+    # roof: measured HBM traffic is about 40 % of peak while VALU instruction issue is at 75-90 % with half the lanes active (counter passes under profiles/ and
+    # a probe build that adds v_nop instructions to the loop).  `achieved` / `frac` price the ALGORITHMIC bytes; traffic_frac = measured HBM bytes / launch time / peak.
     roofline = {"bound": "hbm", "limited_by": "VALU instruction issue of the divergent wave64 traversal (about half the lanes active); measured HBM traffic is ~40 % of peak",
                 "traffic_frac": (round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None),
                 "achieved_is": "a model: counted node steps and primitive tests x the record bytes each reads (the node's cone words, a 16-byte piece only lanes "

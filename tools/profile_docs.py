@@ -66,8 +66,8 @@ TCC_HIT / (HIT + MISS) = %.1f %%; vector-cache accesses %.2f G = %.0f per ray (8
 texture addresser busy %.0f %% of the launch, stalled by the cache %.0f %%; FETCH_SIZE %.2f GB raw = %.2f GB after the gfx950 correction
 (x2: 128-byte requests are tallied at 64 B) + WRITE_SIZE %.2f GB per frame -> %.2f GB per launch (`roofline.traffic`).
 
-Against the collection of round 2 (profiles/r02_pmc_trace_kernel.md, same exact traversal, 32.9 node steps per ray): 4.37 G VALU instructions
-per frame then, i.e. 640 per loop iteration of a wave against about 475 now (the loop lost its second back edge, loads go through buffer
+Against the collection of round 2 (profiles/r02_pmc_trace_kernel.md, same exact traversal, 32.9 node steps per ray): 4.43 G VALU instructions
+per frame then, i.e. 644 per loop iteration of a wave against about 475 now (the loop lost its second back edge, loads go through buffer
 descriptors whose range check replaces the zero-initialised merge registers, the unit-matrix object ray is prepared at refill).
 
 What limits the kernel: VALU instruction issue at about half the lanes active.  A wave iteration is one node step for the lanes at a node
