@@ -73,6 +73,21 @@ def test_c_abi_gather_with_a_one_rank_communicator(rt):
         ctx.close()
 
 
+def test_c_abi_gather_refuses_bad_communicators(rt):
+    """Bad device lists are refused with a code and a message before RCCL is touched."""
+    mg = importlib.import_module("ray-tracer_amd.multigpu")
+    for devices in ([], [99], [0, 0], [-1]):
+        with pytest.raises(rt.RtError) as e:
+            mg.RcclGather(devices=devices)
+        assert e.value.code == rt.abi.RT_ERR_INVALID, devices
+    with pytest.raises(rt.RtError) as e:
+        mg.RcclGather(unique_id=mg.RcclGather.unique_id(), rank=1, world=1, device=0)       # rank outside the world
+    assert e.value.code == rt.abi.RT_ERR_INVALID
+    with pytest.raises(rt.RtError) as e:
+        mg.RcclGather(unique_id=mg.RcclGather.unique_id(), rank=0, world=1, device=99)
+    assert e.value.code == rt.abi.RT_ERR_INVALID
+
+
 @pytest.mark.parametrize("name,tile", [("cornellbox_recursive", 32), ("scienceTree", 8)])
 def test_cpp_host_renders_through_the_gather_library(rt, scene_path, tmp_path, name, tile):
     """host/rt_render --ranks 1: the C++ host (rt_mi355::Mi355NodeRenderer) drives rt_gather_create (ncclCommInitAll), rt_scene_broadcast,
